@@ -1,0 +1,197 @@
+"""ctypes binding of libbackpack_hip.so (C ABI: include/bp_hip.h).
+
+This is the only place where Python touches the native library.  torch is used for what the
+reference's pybind layer used ATen for: device memory, the current stream and output allocation
+(csrc/flash_attn/fmha_api.cpp:211,267-276).  There is NO fallback: if the shared library is
+missing or a call fails, a RuntimeError is raised (the reference raises ImportError /
+RuntimeError in the same situations, flash_attn/flash_attn_interface.py:5).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libbackpack_hip.so')
+ABI_VERSION = 1
+
+_lib = None
+
+_i32, _i64, _f32, _ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol include/bp_hip.h declares
+SIGNATURES = {
+    'bp_strerror': (ctypes.c_char_p, [_i32]),
+    'bp_abi_version': (_i32, []),
+    'bp_flash_fwd': (_i32, [_ptr] * 7 + [_i32] * 5 + [_i64] * 9 + [_f32, _i32, _i32, _ptr]),
+    'bp_attn_probs': (_i32, [_ptr] * 4 + [_i32] * 5 + [_i64] * 10 + [_f32, _i32, _i32, _ptr]),
+    'bp_sense_alpha': (_i32, [_ptr] * 3 + [_i32] * 4 + [_i64] * 4 + [_f32, _i32, _ptr]),
+    'bp_sense_mix': (_i32, [_ptr] * 4 + [_i32] * 5 + [_i64] * 9 + [_f32, _i32, _ptr]),
+}
+
+
+def lib():
+    """Load (once) and return the native library; raise loudly if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} is missing: build it with `python backpacks-flash-attn_amd/build_hip.py` '
+                '(or __graft_entry__.build()).  There is no non-HIP fallback for this path.')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        if handle.bp_abi_version() != ABI_VERSION:
+            raise RuntimeError('libbackpack_hip.so ABI version mismatch; rebuild it')
+        _lib = handle
+    return _lib
+
+
+def is_available():
+    return os.path.exists(LIB_PATH)
+
+
+def _check(code, what):
+    if code != 0:
+        raise RuntimeError(f'{what} failed: {lib().bp_strerror(code).decode()} (code {code})')
+
+
+def _dtype_code(t):
+    if t.dtype == torch.float16:
+        return 0
+    if t.dtype == torch.bfloat16:
+        return 1
+    raise RuntimeError(f'bp_hip: expected fp16 or bf16 tensors, got {t.dtype}')
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('bp_hip: tensors must live on the GPU (no CPU fallback exists)')
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def flash_fwd(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, softmax_scale,
+              causal):
+    """q (total_q,H,D), k/v (total_k,H,D), out like q (written in place); returns
+    softmax_lse (B,H,roundup(max_seqlen_q,16)) fp32.  cu_seqlens_* int32 (B+1) or both None for a
+    fixed-length batch whose size is total_q // max_seqlen_q."""
+    _require_cuda(q, k, v, out, cu_seqlens_q, cu_seqlens_k)
+    if q.dim() != 3 or k.dim() != 3:
+        raise RuntimeError('bp_hip.flash_fwd: q, k, v must be (total, nheads, headdim)')
+    if not (q.dtype == k.dtype and (v is None or (v.dtype == q.dtype and out.dtype == q.dtype))):
+        raise RuntimeError('bp_hip.flash_fwd: q, k, v, out must share one dtype')
+    for t in (q, k, v, out):
+        if t is not None and t.stride(-1) != 1:
+            raise RuntimeError('bp_hip.flash_fwd: last dimension must be contiguous')
+    total_q, nheads, d = q.shape
+    if k.shape[1] != nheads or k.shape[2] != d or (v is not None and v.shape != k.shape):
+        raise RuntimeError('bp_hip.flash_fwd: q/k/v shape mismatch')
+    if v is not None and out.shape != q.shape:
+        raise RuntimeError('bp_hip.flash_fwd: out must have the shape of q')
+    if cu_seqlens_q is not None:
+        for cu in (cu_seqlens_q, cu_seqlens_k):
+            if cu.dtype != torch.int32 or not cu.is_contiguous():
+                raise RuntimeError('bp_hip.flash_fwd: cu_seqlens must be contiguous int32')
+        batch = cu_seqlens_q.numel() - 1
+        if cu_seqlens_k.numel() - 1 != batch:
+            raise RuntimeError('bp_hip.flash_fwd: cu_seqlens_q / cu_seqlens_k length mismatch')
+    else:
+        batch = total_q // max_seqlen_q
+        if batch * max_seqlen_q != total_q or batch * max_seqlen_k != k.shape[0]:
+            raise RuntimeError('bp_hip.flash_fwd: fixed-length batch does not divide total rows')
+    if batch <= 0:
+        raise RuntimeError('bp_hip.flash_fwd: empty batch')
+    lse_len = round_up(max_seqlen_q, 16)
+    lse = torch.empty((batch, nheads, lse_len), dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        code = lib().bp_flash_fwd(
+            q.data_ptr(), k.data_ptr(), v.data_ptr() if v is not None else None,
+            out.data_ptr() if out is not None else None, lse.data_ptr(),
+            cu_seqlens_q.data_ptr() if cu_seqlens_q is not None else None,
+            cu_seqlens_k.data_ptr() if cu_seqlens_k is not None else None,
+            batch, nheads, d, int(max_seqlen_q), int(max_seqlen_k),
+            q.stride(0), q.stride(1), k.stride(0), k.stride(1),
+            v.stride(0) if v is not None else 0, v.stride(1) if v is not None else 0,
+            out.stride(0) if out is not None else 0, out.stride(1) if out is not None else 0,
+            lse_len, float(softmax_scale), int(bool(causal)), _dtype_code(q), _stream())
+    _check(code, 'bp_flash_fwd')
+    return lse
+
+
+def attn_probs(q, k, lse, softmax_scale, causal):
+    """q (B,Sq,H,D), k (B,Sk,H,D) (any batch/row/head strides), lse (B,H,>=Sq) fp32 ->
+    probabilities (B,H,Sq,Sk) in q's dtype."""
+    _require_cuda(q, k, lse)
+    b, sq, h, d = q.shape
+    sk = k.shape[1]
+    if q.stride(-1) != 1 or k.stride(-1) != 1 or not lse.is_contiguous():
+        raise RuntimeError('bp_hip.attn_probs: bad strides')
+    probs = torch.empty((b, h, sq, sk), dtype=q.dtype, device=q.device)
+    with torch.cuda.device(q.device):
+        code = lib().bp_attn_probs(
+            q.data_ptr(), k.data_ptr(), lse.data_ptr(), probs.data_ptr(), b, h, d, sq, sk,
+            q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+            lse.shape[-1], probs.stride(0), probs.stride(1), probs.stride(2),
+            float(softmax_scale), int(bool(causal)), _dtype_code(q), _stream())
+    _check(code, 'bp_attn_probs')
+    return probs
+
+
+def _check_qk(qk):
+    _require_cuda(qk)
+    if qk.dim() != 5 or qk.shape[2] != 2 or qk.stride(-1) != 1:
+        raise RuntimeError('bp_hip: qk must be (B, S, 2, k, d_k) with a contiguous last dim')
+    return qk.shape[0], qk.shape[1], qk.shape[3], qk.shape[4]
+
+
+def sense_alpha(qk, softmax_scale=None):
+    """qk (B,S,2,k,d_k) -> alpha (B,k,S,S), causal softmax over keys, exact zeros above the
+    diagonal (replaces backpack.py:116-122)."""
+    b, s, k, dk = _check_qk(qk)
+    scale = softmax_scale or dk ** -0.5
+    alpha = torch.empty((b, k, s, s), dtype=qk.dtype, device=qk.device)
+    ws = torch.empty((b, k, round_up(s, 16)), dtype=torch.float32, device=qk.device)
+    with torch.cuda.device(qk.device):
+        code = lib().bp_sense_alpha(qk.data_ptr(), alpha.data_ptr(), ws.data_ptr(), b, s, k, dk,
+                                    qk.stride(0), qk.stride(1), qk.stride(2), qk.stride(3),
+                                    float(scale), _dtype_code(qk), _stream())
+    _check(code, 'bp_sense_alpha')
+    return alpha
+
+
+def sense_mix(qk, content, softmax_scale=None, out=None):
+    """Fused sum_l softmax_causal(q_l k_l^T * scale) @ C_l without materialising alpha.
+
+    qk (B,S,2,k,d_k); content in its storage layout (B,S,k,d_out) (the reference's
+    `content` (B,k,S,d_out) is `.transpose(1,2)` of it -- pass that view transposed back, it is
+    free); returns (B,S,d_out).  Replaces backpack.py:305+313."""
+    b, s, k, dk = _check_qk(qk)
+    _require_cuda(content)
+    if content.dim() != 4 or content.shape[:3] != (b, s, k) or content.stride(-1) != 1:
+        raise RuntimeError('bp_hip.sense_mix: content must be (B, S, k, d_out), last dim contiguous')
+    if content.dtype != qk.dtype:
+        raise RuntimeError('bp_hip.sense_mix: qk and content dtypes differ')
+    dout = content.shape[3]
+    scale = softmax_scale or dk ** -0.5
+    if out is None:
+        out = torch.empty((b, s, dout), dtype=qk.dtype, device=qk.device)
+    ws = torch.empty((b, k, round_up(s, 16)), dtype=torch.float32, device=qk.device)
+    with torch.cuda.device(qk.device):
+        code = lib().bp_sense_mix(qk.data_ptr(), content.data_ptr(), out.data_ptr(), ws.data_ptr(),
+                                  b, s, k, dk, dout,
+                                  qk.stride(0), qk.stride(1), qk.stride(2), qk.stride(3),
+                                  content.stride(0), content.stride(1), content.stride(2),
+                                  out.stride(0), out.stride(1),
+                                  float(scale), _dtype_code(qk), _stream())
+    _check(code, 'bp_sense_mix')
+    return out

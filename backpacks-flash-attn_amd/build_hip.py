@@ -1,0 +1,75 @@
+"""Build libbackpack_hip.so (gfx950) in-tree with hipcc.  No torch, no cmake.
+
+    python backpacks-flash-attn_amd/build_hip.py [--force] [--verbose]
+
+Objects land in csrc/build/, the shared library in bp_hip/libbackpack_hip.so (git-ignored, but it
+travels to the GPU box with the repo snapshot).  hipcc cross-compiles without a GPU.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OUT_DIR = os.path.join(CSRC, 'build')
+LIB = os.path.join(HERE, 'bp_hip', 'libbackpack_hip.so')
+SOURCES = ['flash_fwd.hip', 'sense_mix.hip', 'attn_probs.hip', 'bp_api.hip']
+HEADERS = ['bp_common.h', 'bp_kernels.h', os.path.join('..', '..', 'include', 'bp_hip.h')]
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc',
+         '-Wall', '-Wno-unused-variable', '-Wno-unused-but-set-variable']
+
+
+def _hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.sep not in c or os.path.exists(c)):
+            return c
+    raise RuntimeError('hipcc not found')
+
+
+def _stamp():
+    h = hashlib.sha256()
+    for name in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, name), 'rb') as f:
+            h.update(f.read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OUT_DIR, exist_ok=True)
+    stamp_file = os.path.join(OUT_DIR, 'stamp.txt')
+    stamp = _stamp()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp_file):
+        if open(stamp_file).read().strip() == stamp:
+            return LIB
+    hipcc = _hipcc()
+    t0 = time.time()
+
+    def compile_one(src):
+        obj = os.path.join(OUT_DIR, src.replace('.hip', '.o'))
+        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stderr[-8000:]))
+        if verbose and r.stderr:
+            print(r.stderr[-4000:])
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs,
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('link failed:\n' + r.stderr[-8000:])
+    with open(stamp_file, 'w') as f:
+        f.write(stamp)
+    if verbose:
+        print('built %s in %.1fs' % (LIB, time.time() - t0))
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

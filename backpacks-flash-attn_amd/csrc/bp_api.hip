@@ -1,0 +1,196 @@
+// C ABI of libbackpack_hip.so (see include/bp_hip.h for the contract of every entry point).
+// Host-side only: argument validation in the spirit of mha_fwd's TORCH_CHECKs
+// (reference csrc/flash_attn/fmha_api.cpp:206-252), parameter packing, kernel dispatch.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/bp_hip.h"
+#include "bp_common.h"
+#include "bp_kernels.h"
+
+namespace {
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline bool mult8(int64_t x) { return (x & 7) == 0; }
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+inline bool scale_ok(float s) { return isfinite(s) && s > 0.f; }
+
+}  // namespace
+
+extern "C" {
+
+const char *bp_strerror(int code) {
+    switch (code) {
+        case BP_OK: return "ok";
+        case BP_ERR_DTYPE: return "unsupported dtype (expected fp16 or bf16)";
+        case BP_ERR_HEAD_DIM: return "head dimension must be in [1, 128]";
+        case BP_ERR_SHAPE: return "invalid shape or null pointer";
+        case BP_ERR_SCALE: return "softmax_scale must be finite and > 0";
+        case BP_ERR_LAUNCH: return "HIP kernel launch failed";
+        case BP_ERR_DOUT: return "d_out must be >= 1";
+        default: return "unknown error";
+    }
+}
+
+int bp_abi_version(void) { return BP_ABI_VERSION; }
+
+int bp_flash_fwd(const void *q, const void *k, const void *v, void *out, float *softmax_lse,
+                 const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k,
+                 int batch, int nheads, int head_dim, int max_seqlen_q, int max_seqlen_k,
+                 int64_t q_row_stride, int64_t q_head_stride,
+                 int64_t k_row_stride, int64_t k_head_stride,
+                 int64_t v_row_stride, int64_t v_head_stride,
+                 int64_t o_row_stride, int64_t o_head_stride,
+                 int64_t lse_stride, float softmax_scale, int is_causal, int dtype,
+                 bp_stream_t stream) {
+    if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
+    if (head_dim < 1 || head_dim > 128) return BP_ERR_HEAD_DIM;
+    if (batch <= 0 || nheads <= 0 || max_seqlen_q <= 0 || max_seqlen_k < 0) return BP_ERR_SHAPE;
+    if (q == nullptr || k == nullptr || softmax_lse == nullptr) return BP_ERR_SHAPE;
+    if ((v == nullptr) != (out == nullptr)) return BP_ERR_SHAPE;
+    if ((cu_seqlens_q == nullptr) != (cu_seqlens_k == nullptr)) return BP_ERR_SHAPE;
+    if (!scale_ok(softmax_scale)) return BP_ERR_SCALE;
+
+    bp::FlashParams p{};
+    p.q = q; p.k = k; p.v = v; p.o = out; p.lse = softmax_lse;
+    p.cu_q = cu_seqlens_q; p.cu_k = cu_seqlens_k;
+    p.q_rs = q_row_stride; p.q_hs = q_head_stride;
+    p.k_rs = k_row_stride; p.k_hs = k_head_stride;
+    p.v_rs = v_row_stride; p.v_hs = v_head_stride;
+    p.o_rs = o_row_stride; p.o_hs = o_head_stride;
+    p.q_bs = (int64_t)max_seqlen_q * q_row_stride; p.o_bs = (int64_t)max_seqlen_q * o_row_stride;
+    p.k_bs = (int64_t)max_seqlen_k * k_row_stride; p.v_bs = (int64_t)max_seqlen_k * v_row_stride;
+    p.lse_stride = lse_stride;
+    p.b = batch; p.h = nheads; p.d = head_dim;
+    p.max_sq = max_seqlen_q; p.max_sk = max_seqlen_k;
+    p.n_qtiles = (max_seqlen_q + 127) / 128;
+    p.causal = is_causal ? 1 : 0;
+    p.scale_log2e = softmax_scale * bp::kLog2e;
+
+    bool vec = (head_dim % 8 == 0) && aligned16(q) && aligned16(k) && mult8(q_row_stride) &&
+               mult8(q_head_stride) && mult8(k_row_stride) && mult8(k_head_stride);
+    if (v != nullptr)
+        vec = vec && aligned16(v) && aligned16(out) && mult8(v_row_stride) && mult8(v_head_stride) &&
+              mult8(o_row_stride) && mult8(o_head_stride);
+    hipError_t e = bp::launch_flash_fwd(p, dtype, vec, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
+}
+
+int bp_attn_probs(const void *q, const void *k, const float *softmax_lse, void *probs,
+                  int batch, int nheads, int head_dim, int seqlen_q, int seqlen_k,
+                  int64_t q_batch_stride, int64_t q_row_stride, int64_t q_head_stride,
+                  int64_t k_batch_stride, int64_t k_row_stride, int64_t k_head_stride,
+                  int64_t lse_stride,
+                  int64_t p_batch_stride, int64_t p_head_stride, int64_t p_row_stride,
+                  float softmax_scale, int is_causal, int dtype, bp_stream_t stream) {
+    if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
+    if (head_dim < 1 || head_dim > 128) return BP_ERR_HEAD_DIM;
+    if (batch <= 0 || nheads <= 0 || seqlen_q <= 0 || seqlen_k <= 0) return BP_ERR_SHAPE;
+    if (q == nullptr || k == nullptr || softmax_lse == nullptr || probs == nullptr) return BP_ERR_SHAPE;
+    if (!scale_ok(softmax_scale)) return BP_ERR_SCALE;
+
+    bp::ProbsParams p{};
+    p.q = q; p.k = k; p.lse = softmax_lse; p.p = probs;
+    p.q_bs = q_batch_stride; p.q_rs = q_row_stride; p.q_hs = q_head_stride;
+    p.k_bs = k_batch_stride; p.k_rs = k_row_stride; p.k_hs = k_head_stride;
+    p.lse_stride = lse_stride;
+    p.p_bs = p_batch_stride; p.p_hs = p_head_stride; p.p_rs = p_row_stride;
+    p.b = batch; p.h = nheads; p.d = head_dim; p.sq = seqlen_q; p.sk = seqlen_k;
+    p.causal = is_causal ? 1 : 0;
+    p.p_vec = ((reinterpret_cast<uintptr_t>(probs) & 7u) == 0 && (p_batch_stride & 3) == 0 &&
+               (p_head_stride & 3) == 0 && (p_row_stride & 3) == 0) ? 1 : 0;
+    p.scale_log2e = softmax_scale * bp::kLog2e;
+    const bool vec = (head_dim % 8 == 0) && aligned16(q) && aligned16(k) && mult8(q_batch_stride) &&
+                     mult8(q_row_stride) && mult8(q_head_stride) && mult8(k_batch_stride) &&
+                     mult8(k_row_stride) && mult8(k_head_stride);
+    hipError_t e = bp::launch_attn_probs(p, dtype, vec, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
+}
+
+// LSE of every (sense, query): the flash kernel in LSE-only mode with the k senses as heads.
+static int sense_lse(const void *qk, float *lse_ws, int batch, int seqlen, int nsenses, int d_k,
+                     int64_t qk_bs, int64_t qk_rs, int64_t qk_two, int64_t qk_ss,
+                     float softmax_scale, int dtype, hipStream_t stream) {
+    const uint16_t *qp = static_cast<const uint16_t *>(qk);
+    const uint16_t *kp = qp + qk_two;
+    bp::FlashParams p{};
+    p.q = qp; p.k = kp; p.v = nullptr; p.o = nullptr; p.lse = lse_ws;
+    p.cu_q = nullptr; p.cu_k = nullptr;
+    p.q_rs = qk_rs; p.q_hs = qk_ss; p.k_rs = qk_rs; p.k_hs = qk_ss;
+    p.q_bs = qk_bs; p.k_bs = qk_bs;
+    p.lse_stride = round_up(seqlen, 16);
+    p.b = batch; p.h = nsenses; p.d = d_k;
+    p.max_sq = seqlen; p.max_sk = seqlen;
+    p.n_qtiles = (seqlen + 127) / 128;
+    p.causal = 1;
+    p.scale_log2e = softmax_scale * bp::kLog2e;
+    const bool vec = (d_k % 8 == 0) && aligned16(qp) && aligned16(kp) && mult8(qk_bs) && mult8(qk_rs) &&
+                     mult8(qk_ss);
+    hipError_t e = bp::launch_flash_fwd(p, dtype, vec, stream);
+    return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
+}
+
+int bp_sense_alpha(const void *qk, void *alpha, float *lse_ws,
+                   int batch, int seqlen, int nsenses, int d_k,
+                   int64_t qk_batch_stride, int64_t qk_row_stride, int64_t qk_two_stride,
+                   int64_t qk_sense_stride, float softmax_scale, int dtype, bp_stream_t stream) {
+    if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
+    if (d_k < 1 || d_k > 128) return BP_ERR_HEAD_DIM;
+    if (batch <= 0 || nsenses <= 0 || seqlen <= 0) return BP_ERR_SHAPE;
+    if (qk == nullptr || alpha == nullptr || lse_ws == nullptr) return BP_ERR_SHAPE;
+    if (!scale_ok(softmax_scale)) return BP_ERR_SCALE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc = sense_lse(qk, lse_ws, batch, seqlen, nsenses, d_k, qk_batch_stride, qk_row_stride,
+                       qk_two_stride, qk_sense_stride, softmax_scale, dtype, st);
+    if (rc != BP_OK) return rc;
+    const uint16_t *qp = static_cast<const uint16_t *>(qk);
+    const int64_t S = seqlen;
+    return bp_attn_probs(qp, qp + qk_two_stride, lse_ws, alpha, batch, nsenses, d_k, seqlen, seqlen,
+                         qk_batch_stride, qk_row_stride, qk_sense_stride,
+                         qk_batch_stride, qk_row_stride, qk_sense_stride,
+                         round_up(seqlen, 16),
+                         (int64_t)nsenses * S * S, S * S, S,
+                         softmax_scale, 1, dtype, stream);
+}
+
+int bp_sense_mix(const void *qk, const void *content, void *out, float *lse_ws,
+                 int batch, int seqlen, int nsenses, int d_k, int d_out,
+                 int64_t qk_batch_stride, int64_t qk_row_stride, int64_t qk_two_stride,
+                 int64_t qk_sense_stride,
+                 int64_t c_batch_stride, int64_t c_row_stride, int64_t c_sense_stride,
+                 int64_t o_batch_stride, int64_t o_row_stride,
+                 float softmax_scale, int dtype, bp_stream_t stream) {
+    if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
+    if (d_k < 1 || d_k > 128) return BP_ERR_HEAD_DIM;
+    if (d_out < 1) return BP_ERR_DOUT;
+    if (batch <= 0 || nsenses <= 0 || seqlen <= 0) return BP_ERR_SHAPE;
+    if (qk == nullptr || content == nullptr || out == nullptr || lse_ws == nullptr) return BP_ERR_SHAPE;
+    if (!scale_ok(softmax_scale)) return BP_ERR_SCALE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc = sense_lse(qk, lse_ws, batch, seqlen, nsenses, d_k, qk_batch_stride, qk_row_stride,
+                       qk_two_stride, qk_sense_stride, softmax_scale, dtype, st);
+    if (rc != BP_OK) return rc;
+
+    const uint16_t *qp = static_cast<const uint16_t *>(qk);
+    bp::MixParams p{};
+    p.q = qp; p.k = qp + qk_two_stride; p.c = content; p.o = out; p.lse = lse_ws;
+    p.qk_bs = qk_batch_stride; p.qk_rs = qk_row_stride; p.qk_ss = qk_sense_stride;
+    p.c_bs = c_batch_stride; p.c_rs = c_row_stride; p.c_ss = c_sense_stride;
+    p.o_bs = o_batch_stride; p.o_rs = o_row_stride;
+    p.lse_stride = round_up(seqlen, 16);
+    p.b = batch; p.s = seqlen; p.nsenses = nsenses; p.dk = d_k; p.dout = d_out;
+    p.n_qtiles = (seqlen + 255) / 256;
+    p.n_chunks = (d_out + 255) / 256;
+    p.scale_log2e = softmax_scale * bp::kLog2e;
+    const bool vec_qk = (d_k % 8 == 0) && aligned16(p.q) && aligned16(p.k) && mult8(qk_batch_stride) &&
+                        mult8(qk_row_stride) && mult8(qk_sense_stride);
+    const bool vec_c = (d_out % 8 == 0) && aligned16(content) && aligned16(out) && mult8(c_batch_stride) &&
+                       mult8(c_row_stride) && mult8(c_sense_stride) && mult8(o_batch_stride) &&
+                       mult8(o_row_stride);
+    hipError_t e = bp::launch_sense_mix(p, dtype, vec_qk, vec_c, st);
+    return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
+}
+
+}  // extern "C"

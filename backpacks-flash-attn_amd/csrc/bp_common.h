@@ -1,0 +1,130 @@
+// Shared device helpers for the gfx950 (CDNA4) Backpack kernels.
+//
+// Conventions used by every kernel in this directory
+//   * wave = 64 lanes; `hh = lane >> 5` is the half-wave, `l31 = lane & 31`.
+//   * matrix tiles use v_mfma_f32_32x32x16_{bf16,f16}:
+//       A (32 x 16): lane supplies A[l31][8*hh + t], t = 0..7  (8 consecutive K elements)
+//       B (16 x 32): lane supplies B[8*hh + t][l31]
+//       D (32 x 32): reg r of a lane is D[(r&3) + 8*(r>>2) + 4*hh][l31]
+//   * scores are computed TRANSPOSED, S^T = K Q^T, so one lane owns one query column and 16 of
+//     the 32 keys of a block: row max / row sum are in-lane plus ONE exchange with lane^32.
+//   * P^T feeds the second GEMM (O^T = V^T P^T) straight from those registers: regs 8*ks..8*ks+7
+//     are keys {0..3, 8..11} + 4*hh + 16*ks, and the V^T operand is fetched with
+//     ds_read_b64_tr_b16 in the SAME key order, so no cross-lane shuffle of P is needed.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define BP_DEV __device__ __forceinline__
+
+struct BF16 {};
+struct F16 {};
+
+template <class ET> struct Elem;
+
+template <> struct Elem<BF16> {
+    static BP_DEV f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                       __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    static BP_DEV uint32_t pack2(float lo, float hi) {
+        f32x2 x = {lo, hi};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2));
+    }
+    static BP_DEV uint16_t from_float(float x) {
+        return __builtin_bit_cast(uint16_t, (__bf16)x);
+    }
+};
+
+template <> struct Elem<F16> {
+    static BP_DEV f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
+                                                      __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static BP_DEV uint32_t pack2(float lo, float hi) {
+        f32x2 x = {lo, hi};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, f16x2));
+    }
+    static BP_DEV uint16_t from_float(float x) {
+        return __builtin_bit_cast(uint16_t, (_Float16)x);
+    }
+};
+
+// 8 consecutive 16-bit elements as one 16-byte global load (pointer must be 16-B aligned).
+BP_DEV u32x4 ld_global_16B(const uint16_t *p) { return *reinterpret_cast<const u32x4 *>(p); }
+
+// Element-wise loader for rows that are not 16-byte friendly (odd head dims such as d_k = 10).
+// Reads elements [col0, col0+8) of a row of `ncols` valid elements; the rest are zero.
+BP_DEV u32x4 ld_global_8x2B(const uint16_t *row, int col0, int ncols) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = col0 + 2 * i;
+        uint32_t lo = (c < ncols) ? row[c] : 0u;
+        uint32_t hi = (c + 1 < ncols) ? row[c + 1] : 0u;
+        w[i] = lo | (hi << 16);
+    }
+    return u32x4{w[0], w[1], w[2], w[3]};
+}
+
+// LDS accessors on a byte offset into one shared array.
+BP_DEV u32x4 lds_read_16B(const char *smem, int off) {
+    return *reinterpret_cast<const u32x4 *>(smem + off);
+}
+BP_DEV void lds_write_16B(char *smem, int off, u32x4 v) {
+    *reinterpret_cast<u32x4 *>(smem + off) = v;
+}
+// ds_read_b64_tr_b16: within each 16-lane group the 16 x (4 x 16-bit) words are transposed, so a
+// lane that points at row (j>>2), columns 4*(j&3).. of a [4][16] block (j = lane & 15) receives
+// column j of that block: 4 consecutive ROWS of one column.  Address must be 8-byte aligned.
+BP_DEV u32x2 lds_read_tr16_8B(const char *smem, int off) {
+    typedef s16x4 __attribute__((address_space(3))) * lds_ptr_t;
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(smem + off));
+    return __builtin_bit_cast(u32x2, v);
+}
+
+// Byte offset of 16-B chunk `ch` of row `row` in a V / content tile whose rows hold NV 64-byte
+// chunks.  ds_read_b64_tr_b16 serves 32 lanes at once = 4 consecutive rows x 64 B; the XOR on the
+// 64-B chunk index puts those 4 row segments in the 4 different quarters of the 64 banks.
+//   NV=1: rows are 64 B, quarters differ by construction;  NV=3: 192-B rows rotate by 3 quarters.
+template <int NV> BP_DEV int v_lds_off(int row, int ch) {
+    int c64 = ch >> 2;
+    if (NV == 2) c64 ^= (row >> 1) & 1;
+    if (NV == 4 || NV == 8) c64 ^= row & 3;
+    return row * (NV * 64) + ((c64 << 2) | (ch & 3)) * 16;
+}
+
+BP_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+BP_DEV float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+
+// exchange with the other half-wave (lane ^ 32)
+BP_DEV float xhalf(float x) { return __shfl_xor(x, 32); }
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+// XCD-aware work mapping: the dispatcher places block L on XCD L % 8; give every XCD whole
+// `group`s of `per_group` consecutive work items so blocks that share K/V (or C) tiles also
+// share an L2.  Returns false for the padding blocks.
+BP_DEV bool xcd_map(int block, int ngroups, int per_group, int &group, int &item) {
+    const int xcd = block & 7;
+    const int slot = block >> 3;
+    group = (slot / per_group) * 8 + xcd;
+    item = slot % per_group;
+    return group < ngroups;
+}
+inline int xcd_grid(int ngroups, int per_group) { return ((ngroups + 7) / 8) * 8 * per_group; }
+
+}  // namespace bp

@@ -1,0 +1,57 @@
+// Internal launch interface between the C ABI (bp_api.hip) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+namespace bp {
+
+// All strides are in ELEMENTS (16-bit elements for q/k/v/o/c, fp32 for lse).
+struct FlashParams {
+    const void *q, *k, *v;
+    void *o;
+    float *lse;
+    const int *cu_q, *cu_k;   // NULL: fixed length, sequence b at rows [b*max_s, (b+1)*max_s)
+    int64_t q_rs, q_hs, k_rs, k_hs, v_rs, v_hs, o_rs, o_hs;
+    int64_t q_bs, k_bs, v_bs, o_bs;   // batch strides, used only when cu_q == NULL
+    int64_t lse_stride;       // elements between consecutive (batch, head) rows of lse
+    int b, h, d;
+    int max_sq, max_sk;
+    int n_qtiles;             // ceil(max_sq / 128)
+    int causal;
+    float scale_log2e;        // softmax_scale * log2(e)
+};
+
+struct ProbsParams {
+    const void *q, *k;
+    const float *lse;
+    void *p;
+    int64_t q_bs, q_rs, q_hs, k_bs, k_rs, k_hs;
+    int64_t lse_stride;
+    int64_t p_bs, p_hs, p_rs;
+    int b, h, d, sq, sk;
+    int causal;
+    int p_vec;                // 1: 8-byte stores into P are aligned
+    float scale_log2e;
+};
+
+struct MixParams {
+    const void *q, *k;        // q_l[t] = q + b*qk_bs + t*qk_rs + l*qk_ss ; k likewise
+    const void *c;            // content[b, s, l, :] = c + b*c_bs + s*c_rs + l*c_ss
+    void *o;                  // out[b, t, :] = o + b*o_bs + t*o_rs
+    const float *lse;         // (b, k, lse_stride) natural-log LSE of every (sense, query)
+    int64_t qk_bs, qk_rs, qk_ss;
+    int64_t c_bs, c_rs, c_ss;
+    int64_t o_bs, o_rs;
+    int64_t lse_stride;
+    int b, s, nsenses, dk, dout;
+    int n_qtiles;             // ceil(s / 256)
+    int n_chunks;             // ceil(dout / 256)
+    float scale_log2e;
+};
+
+hipError_t launch_flash_fwd(const FlashParams &p, int dtype, bool vec, hipStream_t stream);
+hipError_t launch_attn_probs(const ProbsParams &p, int dtype, bool vec, hipStream_t stream);
+hipError_t launch_sense_mix(const MixParams &p, int dtype, bool vec_qk, bool vec_c, hipStream_t stream);
+
+}  // namespace bp

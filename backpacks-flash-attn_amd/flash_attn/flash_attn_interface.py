@@ -1,0 +1,167 @@
+"""Python API of the fused attention forward -- mirror of the reference's
+flash_attn/flash_attn_interface.py (public functions :242-380), with `flash_attn_cuda.fwd`
+(:23-26) replaced by bp_hip.flash_fwd (C ABI bp_flash_fwd, include/bp_hip.h).
+
+Scope of this build is the FORWARD path: the autograd Functions exist so the
+call sites keep their shape, their backward recomputes attention with differentiable eager ops
+(FA backward kernels are the first "next" row).  Dropout inside the kernel is not implemented;
+`dropout_p` must be 0 as it is in eval / the forward benchmark.
+"""
+import torch
+
+import bp_hip
+
+
+def _get_block_size(device, head_dim, is_dropout):
+    # kept for API compatibility (flash_attn_interface.py:8-10); the HIP kernel tiles 64 keys
+    assert head_dim % 8 == 0 and head_dim <= 128
+    return 64
+
+
+def _flash_attn_forward(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k,
+                        dropout_p, softmax_scale, causal, return_softmax, num_splits=0,
+                        generator=None):
+    """Same contract as the reference's helper (:13-28): writes `out` in place and returns
+    (out, softmax_lse, S_dmask).  `S_dmask` here is the NORMALISED probability tensor
+    (b, h, max_seqlen_q, max_seqlen_k), only for fixed-length batches (testing aid, as upstream)."""
+    if dropout_p != 0.0:
+        raise RuntimeError('flash_attn (gfx950 build): in-kernel dropout is not implemented; '
+                           'call with dropout_p=0.0 (eval mode)')
+    softmax_lse = bp_hip.flash_fwd(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q,
+                                   max_seqlen_k, softmax_scale, causal)
+    S_dmask = None
+    if return_softmax:
+        batch = cu_seqlens_q.numel() - 1
+        if q.shape[0] == batch * max_seqlen_q and k.shape[0] == batch * max_seqlen_k:
+            qb = q.unflatten(0, (batch, max_seqlen_q))
+            kb = k.unflatten(0, (batch, max_seqlen_k))
+            S_dmask = bp_hip.attn_probs(qb, kb, softmax_lse, softmax_scale, causal)
+    return out, softmax_lse, S_dmask
+
+
+def _eager_varlen(q, k, v, cu_q, cu_k, softmax_scale, causal):
+    """Differentiable recomputation used only by backward()."""
+    outs = []
+    cu_q, cu_k = cu_q.tolist(), cu_k.tolist()
+    for b in range(len(cu_q) - 1):
+        qb, kb, vb = q[cu_q[b]:cu_q[b + 1]], k[cu_k[b]:cu_k[b + 1]], v[cu_k[b]:cu_k[b + 1]]
+        s = torch.einsum('thd,shd->hts', qb.float(), kb.float()) * softmax_scale
+        if causal:
+            mask = torch.ones(s.shape[-2:], dtype=torch.bool, device=s.device).triu(1)
+            s = s.masked_fill(mask, float('-inf'))
+        p = torch.softmax(s, dim=-1) if kb.shape[0] > 0 else s
+        outs.append(torch.einsum('hts,shd->thd', p, vb.float()).to(q.dtype))
+    return torch.cat(outs, dim=0)
+
+
+class _FlashAttnFuncBase(torch.autograd.Function):
+    """forward = HIP kernel; backward = autograd through `_eager_varlen` (see module docstring)."""
+
+    @staticmethod
+    def _fwd(ctx, q, k, v, cu_q, cu_k, max_q, max_k, dropout_p, softmax_scale, causal, return_softmax):
+        if softmax_scale is None:
+            softmax_scale = q.shape[-1] ** (-0.5)
+        out, lse, S = _flash_attn_forward(q, k, v, torch.empty_like(q), cu_q, cu_k, max_q, max_k,
+                                          dropout_p, softmax_scale, causal, return_softmax)
+        ctx.softmax_scale, ctx.causal = softmax_scale, causal
+        return out, lse, S
+
+    @staticmethod
+    def _bwd(ctx, dout, q, k, v, cu_q, cu_k):
+        with torch.enable_grad():
+            q_, k_, v_ = (t.detach().requires_grad_() for t in (q, k, v))
+            out = _eager_varlen(q_, k_, v_, cu_q, cu_k, ctx.softmax_scale, ctx.causal)
+            return torch.autograd.grad(out, (q_, k_, v_), dout)
+
+
+class FlashAttnQKVPackedFunc(_FlashAttnFuncBase):
+
+    @staticmethod
+    def forward(ctx, qkv, cu_seqlens, max_seqlen, dropout_p, softmax_scale, causal, return_softmax):
+        out, lse, S = _FlashAttnFuncBase._fwd(ctx, qkv[:, 0], qkv[:, 1], qkv[:, 2], cu_seqlens,
+                                              cu_seqlens, max_seqlen, max_seqlen, dropout_p,
+                                              softmax_scale, causal, return_softmax)
+        ctx.save_for_backward(qkv, cu_seqlens)
+        return out if not return_softmax else (out, lse, S)
+
+    @staticmethod
+    def backward(ctx, dout, *args):
+        qkv, cu = ctx.saved_tensors
+        dq, dk, dv = _FlashAttnFuncBase._bwd(ctx, dout, qkv[:, 0], qkv[:, 1], qkv[:, 2], cu, cu)
+        return torch.stack([dq, dk, dv], dim=1), None, None, None, None, None, None
+
+
+class FlashAttnKVPackedFunc(_FlashAttnFuncBase):
+
+    @staticmethod
+    def forward(ctx, q, kv, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p,
+                softmax_scale, causal, return_softmax):
+        out, lse, S = _FlashAttnFuncBase._fwd(ctx, q, kv[:, 0], kv[:, 1], cu_seqlens_q, cu_seqlens_k,
+                                              max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale,
+                                              causal, return_softmax)
+        ctx.save_for_backward(q, kv, cu_seqlens_q, cu_seqlens_k)
+        return out if not return_softmax else (out, lse, S)
+
+    @staticmethod
+    def backward(ctx, dout, *args):
+        q, kv, cu_q, cu_k = ctx.saved_tensors
+        dq, dk, dv = _FlashAttnFuncBase._bwd(ctx, dout, q, kv[:, 0], kv[:, 1], cu_q, cu_k)
+        return dq, torch.stack([dk, dv], dim=1), None, None, None, None, None, None, None, None
+
+
+class FlashAttnFunc(_FlashAttnFuncBase):
+
+    @staticmethod
+    def forward(ctx, q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p,
+                softmax_scale, causal, return_softmax):
+        out, lse, S = _FlashAttnFuncBase._fwd(ctx, q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q,
+                                              max_seqlen_k, dropout_p, softmax_scale, causal,
+                                              return_softmax)
+        ctx.save_for_backward(q, k, v, cu_seqlens_q, cu_seqlens_k)
+        return out if not return_softmax else (out, lse, S)
+
+    @staticmethod
+    def backward(ctx, dout, *args):
+        q, k, v, cu_q, cu_k = ctx.saved_tensors
+        dq, dk, dv = _FlashAttnFuncBase._bwd(ctx, dout, q, k, v, cu_q, cu_k)
+        return dq, dk, dv, None, None, None, None, None, None, None, None
+
+
+def flash_attn_unpadded_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p, softmax_scale=None,
+                                       causal=False, return_attn_probs=False):
+    """qkv (total, 3, nheads, headdim); cu_seqlens int32 (batch+1); returns out (total, nheads,
+    headdim) [, softmax_lse (batch, nheads, seqlen), probs].  Reference: :242-267."""
+    return FlashAttnQKVPackedFunc.apply(qkv, cu_seqlens, max_seqlen, dropout_p, softmax_scale,
+                                        causal, return_attn_probs)
+
+
+def flash_attn_unpadded_kvpacked_func(q, kv, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k,
+                                      dropout_p, softmax_scale=None, causal=False,
+                                      return_attn_probs=False):
+    """q (total_q, nheads, headdim), kv (total_k, 2, nheads, headdim).  Reference: :270-300."""
+    return FlashAttnKVPackedFunc.apply(q, kv, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k,
+                                       dropout_p, softmax_scale, causal, return_attn_probs)
+
+
+def flash_attn_unpadded_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k,
+                             dropout_p, softmax_scale=None, causal=False, return_attn_probs=False):
+    """q (total_q, nheads, headdim), k, v (total_k, nheads, headdim).  Reference: :303-334."""
+    return FlashAttnFunc.apply(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k,
+                               dropout_p, softmax_scale, causal, return_attn_probs)
+
+
+def flash_attn_unpadded_qkvpacked_split_func(qkv, cu_seqlens, max_seqlen0, max_seqlen1, batch_size0,
+                                             dropout_p, softmax_scale=None, causal=False,
+                                             return_attn_probs=False):
+    """Reference :337-371 splits the batch into two launches on two streams so short sequences
+    do not pay for long ones.  The HIP kernel exits per (sequence, tile) on its own, so one launch
+    covers both parts; the signature is kept."""
+    return flash_attn_unpadded_qkvpacked_func(qkv, cu_seqlens, max(max_seqlen0, max_seqlen1),
+                                              dropout_p, softmax_scale, causal, return_attn_probs)
+
+
+def flash_attn_func(qkv, cu_seqlens, dropout_p, max_s, softmax_scale=None, causal=False,
+                    return_attn_probs=False):
+    """Backward-compatibility alias (reference :374-380)."""
+    return flash_attn_unpadded_qkvpacked_func(qkv, cu_seqlens, max_s, dropout_p, softmax_scale,
+                                              causal, return_attn_probs)

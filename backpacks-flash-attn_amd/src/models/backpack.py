@@ -1,0 +1,200 @@
+"""Backpack language model (Hewitt et al., ACL 2023) -- MI355X-native mirror of the reference's
+training/src/models/backpack.py: same classes, constructor arguments, attribute names and
+state-dict keys (BackpackConfig :146-154, ContextSelfAttn :94-122, BackpackContentModule :207-276,
+BackpackModel :278-314, BackpackLMHeadModel :318-351).
+
+What differs is HOW the forward runs when `config.use_flash_attn` is set (the reference's own
+switch for its native path, flash_attn/models/gpt.py:56):
+  * every trunk layer's attention is one launch of the HIP flash kernel (bp_flash_fwd);
+  * `BackpackModel.forward` never materialises the (B,k,S,S) sense weights: the causal softmax and
+    `torch.sum(alpha @ content, dim=1)` (reference :305,:313) are one fused HIP contraction
+    (bp_sense_mix);
+  * `ContextSelfAttn.forward` still returns alpha (B,k,S,S) for the callers that edit it
+    (training/src/models/intervened_models.py:78-101), produced by bp_sense_alpha.
+With `use_flash_attn=False` the modules run the reference's eager op sequence (any device/dtype) --
+its "non-optimized" mode (training/demo_convert.py:7-20).  The flag alone decides; nothing falls
+back silently, and the HIP path raises if its inputs are not 16-bit CUDA tensors.
+"""
+import math
+from collections import namedtuple
+from functools import partial
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from transformers import GPT2Config
+
+import bp_hip
+from flash_attn.models.gpt import GPTModel, GPTPreTrainedModel, _activation, _init_weights, _pad_vocab
+from flash_attn.modules.block import Block
+from flash_attn.modules.mlp import Mlp
+
+
+class BackpackConfig(GPT2Config):
+
+    def __init__(self, num_content_vectors=16, **kwargs):
+        self.num_content_vectors = num_content_vectors
+        super().__init__(**kwargs)
+
+
+def create_content_mlp_cls(config, layer_idx=None, expand_out=False, process_group=None,
+                           device=None, dtype=None):
+    """MLP d -> inner -> (k*d if expand_out else d); inner = d when `shrink_final_inner`
+    (reference :53-92)."""
+    assert process_group is None
+    inner_dim = config.n_inner if config.n_inner is not None else 4 * config.hidden_size
+    if getattr(config, 'shrink_final_inner', None):
+        inner_dim = config.hidden_size
+    outer_dim = config.num_content_vectors * config.hidden_size if expand_out else config.hidden_size
+    return partial(Mlp, hidden_features=inner_dim, out_features=outer_dim,
+                   activation=_activation(config), device=device, dtype=dtype)
+
+
+class Identity(nn.Identity):
+    """Mixer of the content model's block: passes its input through (reference :125-128)."""
+
+    def forward(self, x, **kwargs):
+        return x
+
+
+def create_nomix_block(config, expand_out=False, layer_idx=None, process_group=None, device=None,
+                       dtype=None):
+    mlp_cls = create_content_mlp_cls(config, layer_idx, expand_out, device=device, dtype=dtype)
+    norm_cls = partial(nn.LayerNorm, eps=config.layer_norm_epsilon, device=device, dtype=dtype)
+    block = Block(config.hidden_size, Identity, mlp_cls, norm_cls=norm_cls, prenorm=True,
+                  resid_dropout=config.resid_pdrop,
+                  fused_dropout_add_ln=getattr(config, 'fused_dropout_add_ln', False))
+    block.layer_idx = layer_idx
+    return block
+
+
+class ContextSelfAttn(nn.Module):
+    """num_content_vectors causal attention maps per pair of positions (reference :94-122).
+
+    forward(encoded (B,S,d)) -> alpha (B,k,S,S) in the activation dtype.
+    `project(encoded)` -> qk (B,S,2,k,d/k) is the half that `BackpackModel` feeds to the fused mix.
+    """
+
+    def __init__(self, num_content_vectors, embed_dim, device=None, dtype=None, use_hip=False):
+        super().__init__()
+        # the reference uses FusedDense here (:102); its forward is F.linear with the same
+        # parameter names (flash_attn/ops/fused_dense.py:110-129)
+        self.Wqkv = nn.Linear(embed_dim, 2 * embed_dim, device=device, dtype=dtype)
+        self.num_content_vectors = num_content_vectors
+        self.softmax_scale = None
+        self.use_hip = use_hip
+
+    def project(self, encoded):
+        b, s, d = encoded.shape
+        k = self.num_content_vectors
+        return self.Wqkv(encoded).reshape(b, s, 2, k, d // k)
+
+    def forward(self, encoded):
+        qk = self.project(encoded)
+        if self.use_hip:
+            return bp_hip.sense_alpha(qk, self.softmax_scale)
+        seqlen = qk.shape[1]
+        q, k = qk.unbind(dim=2)
+        scale = self.softmax_scale or 1.0 / math.sqrt(q.shape[-1])
+        scores = torch.einsum('bthd,bshd->bhts', q, k * scale)
+        mask = torch.triu(torch.full((seqlen, seqlen), -10000.0, device=scores.device), 1)
+        scores = scores + mask.to(dtype=scores.dtype)
+        return torch.softmax(scores, dim=-1, dtype=q.dtype)
+
+
+class BackpackPreTrainedModel(nn.Module):
+
+    def __init__(self, config, *inputs, **kwargs):
+        super().__init__()
+        if not isinstance(config, BackpackConfig):
+            raise ValueError('config must be a BackpackConfig, got %r' % type(config))
+        self.config = config
+
+
+class BackpackContentModule(nn.Module):
+    """Sense vectors C(x): word embedding (no positions) -> LN -> one no-mix block -> final MLP
+    d -> k*d, returned as the (B,k,S,d) view of the contiguous (B,S,k*d) buffer (reference :251-276).
+    That buffer layout is the input contract of bp_sense_mix."""
+
+    def __init__(self, config, num_content_vectors, embeddings, process_group=None, device=None,
+                 dtype=None):
+        super().__init__()
+        assert process_group is None
+        factory_kwargs = {'device': device, 'dtype': dtype}
+        self.num_content_vectors = num_content_vectors
+        self.embeddings = embeddings
+        self.process_group = None
+        self.n_embd = config.n_embd
+        self.fused_dropout_add_ln = getattr(config, 'fused_dropout_add_ln', False)
+        self.ln_0 = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_epsilon, **factory_kwargs)
+        n_layers = 1
+        self.layers = nn.ModuleList([create_nomix_block(config, layer_idx=i, expand_out=False,
+                                                        **factory_kwargs) for i in range(n_layers)])
+        self.final_mlp = create_content_mlp_cls(config, layer_idx=n_layers + 1, expand_out=True,
+                                                **factory_kwargs)(config.n_embd)
+        self.emb_drop = nn.Dropout(config.embd_pdrop)
+        self.apply(partial(_init_weights, n_layer=n_layers, initializer_range=config.initializer_range))
+
+    def forward(self, input_ids, position_ids=None, inference_params=None):
+        hidden = self.embeddings.word_embeddings(input_ids)          # no positions (reference :258)
+        residual = self.emb_drop(hidden).float()
+        hidden = self.ln_0(residual.to(dtype=self.ln_0.weight.dtype))
+        for layer in self.layers:
+            hidden, residual = layer(hidden, residual)
+        hidden = self.final_mlp(hidden)                               # (B, S, k*d)
+        bs, s, _ = hidden.shape
+        return hidden.reshape(bs, s, self.num_content_vectors, self.n_embd).transpose(1, 2)
+
+
+class BackpackModel(GPTPreTrainedModel):
+
+    def __init__(self, config: BackpackConfig, process_group=None, device=None, dtype=None):
+        super().__init__(config)
+        assert process_group is None, 'tensor parallelism is out of scope for the Backpack path'
+        factory_kwargs = {'device': device, 'dtype': dtype}
+        self.process_group = None
+        assert config.activation_function in ('gelu', 'gelu_new', 'gelu_fast')
+        self.pad_vocab_size_multiple = _pad_vocab(config)
+        self.use_hip = bool(getattr(config, 'use_flash_attn', False))
+        self.num_content_vectors = config.num_content_vectors
+        self.gpt2_model = GPTModel(config, **factory_kwargs)
+        self.content_model = BackpackContentModule(config, self.num_content_vectors,
+                                                   self.gpt2_model.embeddings, **factory_kwargs)
+        self.embeddings = self.gpt2_model.embeddings   # shared with the contextualisation model
+        self.contextualization_attn = ContextSelfAttn(self.num_content_vectors, config.n_embd,
+                                                      use_hip=self.use_hip, **factory_kwargs)
+
+    def forward(self, input_ids, position_ids=None, inference_params=None):
+        contextl_hidden_states = self.gpt2_model(input_ids, position_ids=position_ids,
+                                                 inference_params=inference_params)
+        content = self.content_model(input_ids, position_ids, inference_params)   # (B,k,S,d) view
+        if self.use_hip:
+            # fused: softmax_causal(q_l k_l^T) @ C_l summed over senses, alpha never stored
+            qk = self.contextualization_attn.project(contextl_hidden_states)
+            return bp_hip.sense_mix(qk, content.transpose(1, 2),
+                                    self.contextualization_attn.softmax_scale)
+        contextualization = self.contextualization_attn(contextl_hidden_states)   # (B,k,S,S)
+        return torch.sum(contextualization @ content, dim=1)                       # (B,S,d)
+
+
+class BackpackLMHeadModel(BackpackPreTrainedModel):
+
+    def __init__(self, config: BackpackConfig, process_group=None, device=None, dtype=None):
+        super().__init__(config)
+        assert process_group is None
+        self.process_group = None
+        self.transformer = BackpackModel(config, device=device, dtype=dtype)
+        self.lm_head = nn.Linear(config.n_embd, config.vocab_size, bias=False, device=device, dtype=dtype)
+        self.apply(partial(_init_weights, n_layer=config.num_hidden_layers,
+                           initializer_range=config.initializer_range))
+        self.tie_weights()
+
+    def tie_weights(self):
+        # tied with the word embeddings of both the trunk and the content model (reference :339-340)
+        self.lm_head.weight = self.transformer.embeddings.word_embeddings.weight
+
+    def forward(self, input_ids, position_ids=None, inference_params=None):
+        hidden_states = self.transformer(input_ids, position_ids=position_ids,
+                                         inference_params=inference_params)
+        CausalLMOutput = namedtuple('CausalLMOutput', ['logits'])
+        return CausalLMOutput(logits=self.lm_head(hidden_states))

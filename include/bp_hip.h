@@ -1,0 +1,125 @@
+/*
+ * bp_hip.h -- C ABI of libbackpack_hip.so: the MI355X (gfx950) implementation of the
+ * Backpack forward hot path.
+ *
+ * The reference (john-hewitt/backpacks-flash-attn) has no C ABI: its native boundary is the
+ * pybind11 module `flash_attn_cuda` (csrc/flash_attn/fmha_api.cpp:776-782) taking at::Tensor,
+ * and its Backpack-specific ops are eager ATen calls (training/src/models/backpack.py:107-122,313).
+ * Every entry point below names the reference interface it replaces.  All of them
+ *   - take raw DEVICE pointers, explicit sizes and int64 ELEMENT strides (no torch types),
+ *   - allocate nothing and keep no state (re-entrant; scratch is passed in by the caller),
+ *   - enqueue on the given hipStream_t and return without synchronising,
+ *   - return 0 on success or a negative BP_ERR_* (the Python layer raises RuntimeError, which
+ *     is what TORCH_CHECK failures surface as in the reference: fmha_api.cpp:206-250).
+ */
+#ifndef BP_HIP_H
+#define BP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BP_ABI_VERSION 1
+
+/* element type of q/k/v/out/content tensors */
+#define BP_DTYPE_F16 0
+#define BP_DTYPE_BF16 1
+
+#define BP_OK 0
+#define BP_ERR_DTYPE -1       /* dtype is not BP_DTYPE_F16 / BP_DTYPE_BF16         (fmha_api.cpp:215-219) */
+#define BP_ERR_HEAD_DIM -2    /* head_dim < 1 or > 128                              (fmha_api.cpp:245)     */
+#define BP_ERR_SHAPE -3       /* batch/nheads/seqlen <= 0, or a required pointer is NULL (fmha_api.cpp:244-252) */
+#define BP_ERR_SCALE -4       /* softmax_scale is not finite or not > 0                                     */
+#define BP_ERR_LAUNCH -5      /* hipLaunchKernel failed (FMHA_CHECK_CUDA, src/fmha_utils.h:39)              */
+#define BP_ERR_DOUT -6        /* sense mix: d_out < 1                                                       */
+
+typedef void *bp_stream_t; /* a hipStream_t */
+
+/* Human-readable text for a BP_ERR_* code (static storage). */
+const char *bp_strerror(int code);
+int bp_abi_version(void);
+
+/*
+ * bp_flash_fwd -- fused attention forward  O = softmax(scale * Q K^T [+ causal mask]) V  and the
+ * row log-sum-exp.  Replaces flash_attn_cuda.fwd / mha_fwd (csrc/flash_attn/fmha_api.cpp:189-325),
+ * no-dropout path; called by _flash_attn_forward (flash_attn/flash_attn_interface.py:13-28).
+ *
+ *   q            (total_q, nheads, head_dim) 16-bit, last stride 1; row/head strides free
+ *   k, v         (total_k, nheads, head_dim) likewise.  v == NULL and out == NULL: LSE only.
+ *   out          (total_q, nheads, head_dim), caller-allocated, written in place
+ *   softmax_lse  (batch, nheads, lse_stride) fp32, natural log; -inf for a row with no key;
+ *                entries >= that sequence's length are left untouched (fmha_api.cpp:276)
+ *   cu_seqlens_* int32 (batch+1) device arrays of row offsets; NULL means fixed length:
+ *                sequence b occupies rows [b*max_seqlen, (b+1)*max_seqlen)
+ *   is_causal    mask is top-left aligned: key j visible to query i iff j <= i
+ *                (csrc/flash_attn/src/fmha/mask.h:57-70)
+ * Any head_dim in [1,128] is accepted; the 16-byte vector path needs head_dim % 8 == 0 with
+ * 16-byte aligned rows (the reference's only mode), other shapes take an element-wise loader.
+ */
+int bp_flash_fwd(const void *q, const void *k, const void *v, void *out, float *softmax_lse,
+                 const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k,
+                 int batch, int nheads, int head_dim, int max_seqlen_q, int max_seqlen_k,
+                 int64_t q_row_stride, int64_t q_head_stride,
+                 int64_t k_row_stride, int64_t k_head_stride,
+                 int64_t v_row_stride, int64_t v_head_stride,
+                 int64_t o_row_stride, int64_t o_head_stride,
+                 int64_t lse_stride, float softmax_scale, int is_causal, int dtype,
+                 bp_stream_t stream);
+
+/*
+ * bp_attn_probs -- materialise normalised attention probabilities
+ *   P[b,h,i,j] = exp(scale * q_i.k_j - lse[b,h,i])  for visible (i,j), exactly 0 elsewhere.
+ * Serves `return_attn_probs=True` of the flash interface (flash_attn_interface.py:242-267; the
+ * reference returns S_dmask from the same launch, fmha_api.cpp:279,322-324) and is the second pass
+ * of bp_sense_alpha.  Fixed-length batches only.
+ *   probs (batch, nheads, seqlen_q, seqlen_k) 16-bit, strides p_batch/p_head/p_row, last stride 1.
+ */
+int bp_attn_probs(const void *q, const void *k, const float *softmax_lse, void *probs,
+                  int batch, int nheads, int head_dim, int seqlen_q, int seqlen_k,
+                  int64_t q_batch_stride, int64_t q_row_stride, int64_t q_head_stride,
+                  int64_t k_batch_stride, int64_t k_row_stride, int64_t k_head_stride,
+                  int64_t lse_stride,
+                  int64_t p_batch_stride, int64_t p_head_stride, int64_t p_row_stride,
+                  float softmax_scale, int is_causal, int dtype, bp_stream_t stream);
+
+/*
+ * bp_sense_alpha -- Backpack contextualisation weights
+ *   alpha[b,l,t,s] = softmax_s( q_l[t].k_l[s] * scale ) over s <= t, 0 for s > t.
+ * Replaces the eager body of ContextSelfAttn.forward after its Wqkv projection
+ * (training/src/models/backpack.py:112-122).
+ *   qk     (batch, seqlen, 2, nsenses, d_k) 16-bit: the Wqkv output viewed as in backpack.py:111;
+ *          element strides qk_batch/qk_row/qk_two/qk_sense, last stride 1
+ *   alpha  (batch, nsenses, seqlen, seqlen) 16-bit contiguous, caller-allocated
+ *   lse_ws fp32 scratch, batch * nsenses * roundup(seqlen,16) elements
+ */
+int bp_sense_alpha(const void *qk, void *alpha, float *lse_ws,
+                   int batch, int seqlen, int nsenses, int d_k,
+                   int64_t qk_batch_stride, int64_t qk_row_stride, int64_t qk_two_stride,
+                   int64_t qk_sense_stride, float softmax_scale, int dtype, bp_stream_t stream);
+
+/*
+ * bp_sense_mix -- fused sense-weighted combination, alpha never materialised:
+ *   out[b,t,:] = sum_l sum_{s<=t} alpha[b,l,t,s] * content[b,s,l,:]
+ * Replaces `torch.sum(contextualization @ content, dim=1)` together with the softmax that
+ * produced `contextualization` (training/src/models/backpack.py:305,313).
+ *   qk       as in bp_sense_alpha
+ *   content  (batch, seqlen, nsenses, d_out) 16-bit -- the (B,S,k*d) output of the content
+ *            model's final MLP before its reshape/transpose (backpack.py:274-276); element strides
+ *            c_batch/c_row/c_sense, last stride 1.  d_out is free (vocab-sized content works).
+ *   out      (batch, seqlen, d_out) 16-bit, strides o_batch/o_row
+ *   lse_ws   fp32 scratch, batch * nsenses * roundup(seqlen,16) elements
+ */
+int bp_sense_mix(const void *qk, const void *content, void *out, float *lse_ws,
+                 int batch, int seqlen, int nsenses, int d_k, int d_out,
+                 int64_t qk_batch_stride, int64_t qk_row_stride, int64_t qk_two_stride,
+                 int64_t qk_sense_stride,
+                 int64_t c_batch_stride, int64_t c_row_stride, int64_t c_sense_stride,
+                 int64_t o_batch_stride, int64_t o_row_stride,
+                 float softmax_scale, int dtype, bp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BP_HIP_H */

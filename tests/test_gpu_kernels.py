@@ -1,0 +1,274 @@
+"""-m gpu parity tests of the HIP kernels (through the C ABI) against the CPU oracle.
+
+Criterion for 16-bit floating point (the reference's own, tests/test_flash_attn.py:424-428):
+    max|kernel - fp32 oracle|  <=  2 * max|same-dtype eager PyTorch - fp32 oracle|  (+ tiny atol)
+Causal-mask / indexing properties are checked bit-exactly (zeros above the diagonal, -inf LSE,
+untouched padding rows).
+"""
+import math
+
+import pytest
+import torch
+
+from conftest import from_bits16, load_golden
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+def _bp():
+    import bp_hip
+    return bp_hip
+
+
+def rel_check(got, ref32, eager16, name, factor=2.0, atol=1e-5):
+    err = (got.float().cpu() - ref32.float().cpu()).abs().max().item()
+    base = (eager16.float().cpu() - ref32.float().cpu()).abs().max().item()
+    print(f'{name}: kernel err {err:.3e}  eager-same-dtype err {base:.3e}')
+    assert err <= factor * base + atol, f'{name}: {err} > {factor} * {base}'
+    assert torch.isfinite(got.float()).all()
+
+
+def run_flash_fixed(qkv, scale, causal):
+    """qkv (B,S,3,H,D) on GPU -> out (B,S,H,D), lse (B,H,S)."""
+    bp = _bp()
+    b, s, _, h, d = qkv.shape
+    flat = qkv.reshape(b * s, 3, h, d)
+    out = torch.empty_like(flat[:, 0])
+    cu = torch.arange(0, (b + 1) * s, s, dtype=torch.int32, device=qkv.device)
+    lse = bp.flash_fwd(flat[:, 0], flat[:, 1], flat[:, 2], out, cu, cu, s, s, scale, causal)
+    return out.reshape(b, s, h, d), lse[:, :, :s]
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('causal', [True, False])
+@pytest.mark.parametrize('d', [64, 80, 128, 32, 16, 40])
+@pytest.mark.parametrize('seqlen', [97, 128, 200, 256, 257, 1024])
+def test_flash_fwd_fixed_len(seqlen, d, causal, dtype):
+    """Shape sweep of the reference's test_flash_attn_unpadded_qkvpacked (tests/test_flash_attn.py:350-373)."""
+    torch.manual_seed(0)
+    b, h = 3, 4
+    qkv32 = torch.randn(b, seqlen, 3, h, d)
+    qkv16 = qkv32.to(dtype)
+    scale = 1.0 / math.sqrt(d)
+    ref, _, lse_ref = R.attention_fp32(qkv16[:, :, 0], qkv16[:, :, 1], qkv16[:, :, 2], causal=causal,
+                                       softmax_scale=scale)
+    ref32 = R.attention_fp32(qkv16[:, :, 0].float(), qkv16[:, :, 1].float(), qkv16[:, :, 2].float(),
+                             causal=causal, softmax_scale=scale)[0]
+    eager, _, _ = R.attention_fp32(qkv16[:, :, 0], qkv16[:, :, 1], qkv16[:, :, 2], causal=causal,
+                                   softmax_scale=scale, upcast=False, reorder_ops=True)
+    out, lse = run_flash_fixed(qkv16.to(DEV), scale, causal)
+    rel_check(out, ref32, eager, f'flash s={seqlen} d={d} causal={causal} {dtype}')
+    assert (lse.cpu() - lse_ref).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize('layer', [0, 5, 11])
+@pytest.mark.parametrize('tag', ['h64', 'h80'])
+def test_flash_fwd_golden_trunk(tag, layer):
+    """G3: the reference's eager SelfAttention output at the trunk's per-layer scale."""
+    g = load_golden('g3_trunk_attn.npz')
+    qkv = from_bits16(g[f'{tag}_qkv'])
+    want = torch.from_numpy(g[f'{tag}_L{layer}_out'])
+    lse_want = torch.from_numpy(g[f'{tag}_L{layer}_lse'])
+    dh = qkv.shape[-1]
+    scale = dh ** -0.5 / (layer + 1)
+    out, lse = run_flash_fixed(qkv.to(DEV, torch.bfloat16), scale, True)
+    eager = R.self_attention_eager(qkv.bfloat16(), True, scale)
+    rel_check(out, want, eager, f'golden {tag} L{layer}')
+    assert (lse.cpu() - lse_want).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize('causal', [False, True])
+def test_flash_fwd_varlen_golden(causal):
+    """G5: unequal lengths (97,128,33,1) through cu_seqlens; padding rows of LSE stay untouched."""
+    bp = _bp()
+    g = load_golden('g5_varlen.npz')
+    qkv = from_bits16(g['qkv_unpad']).to(DEV, torch.bfloat16)
+    cu = torch.from_numpy(g['cu_seqlens']).to(DEV, torch.int32)
+    max_s = int(g['max_s'])
+    out = torch.full_like(qkv[:, 0], float('nan'))
+    lse = bp.flash_fwd(qkv[:, 0], qkv[:, 1], qkv[:, 2], out, cu, cu, max_s, max_s, 64 ** -0.5, causal)
+    want = torch.from_numpy(g[f'out_causal{int(causal)}'])
+    err = (out.float().cpu() - want).abs().max().item()
+    assert err < 2e-2, err
+    lens = g['lens']
+    lse_want = torch.from_numpy(g[f'lse_causal{int(causal)}'])  # (H, total)
+    off = 0
+    for b, n in enumerate(lens):
+        got = lse[b, :, :n].cpu()
+        assert (got - lse_want[:, off:off + n]).abs().max().item() < 2e-3
+        off += n
+
+
+def test_flash_fwd_cross_and_empty():
+    """seqlen_q != seqlen_k (kv-packed style) and a sequence with zero keys -> zeros / -inf LSE."""
+    bp = _bp()
+    torch.manual_seed(3)
+    h, d = 2, 64
+    lens_q = [70, 5, 130]
+    lens_k = [33, 0, 200]
+    q = torch.randn(sum(lens_q), h, d).bfloat16()
+    k = torch.randn(sum(lens_k), h, d).bfloat16()
+    v = torch.randn(sum(lens_k), h, d).bfloat16()
+    cu_q = torch.tensor([0] + list(torch.tensor(lens_q).cumsum(0)), dtype=torch.int32)
+    cu_k = torch.tensor([0] + list(torch.tensor(lens_k).cumsum(0)), dtype=torch.int32)
+    for causal in (False, True):
+        want, lses = R.varlen_attention_fp32(q, k, v, cu_q, cu_k, causal=causal)
+        out = torch.empty_like(q, device=DEV)
+        lse = bp.flash_fwd(q.to(DEV), k.to(DEV), v.to(DEV), out, cu_q.to(DEV), cu_k.to(DEV),
+                           max(lens_q), max(lens_k), d ** -0.5, causal)
+        assert (out.float().cpu() - want.float()).abs().max().item() < 2e-2
+        assert torch.equal(out[70:75].cpu(), torch.zeros(5, h, d, dtype=torch.bfloat16))
+        assert torch.isinf(lse[1, :, :5]).all() and (lse[1, :, :5] < 0).all()
+        assert (lse[0, :, :70].cpu() - lses[0]).abs().max().item() < 2e-3
+
+
+def test_flash_fwd_determinism():
+    """10 repeats bit-identical (reference race test, tests/test_flash_attn.py:774-793)."""
+    torch.manual_seed(1)
+    qkv = torch.randn(4, 300, 3, 4, 64, device=DEV).bfloat16()
+    o0, l0 = run_flash_fixed(qkv, 0.125, True)
+    for _ in range(10):
+        o, l = run_flash_fixed(qkv, 0.125, True)
+        assert torch.equal(o, o0) and torch.equal(l, l0)
+
+
+def test_flash_fwd_forced_rescale():
+    """A key that spikes late in the sequence forces the online-softmax rescale branch."""
+    torch.manual_seed(5)
+    b, s, h, d = 1, 512, 2, 64
+    qkv = torch.randn(b, s, 3, h, d) * 0.5
+    qkv[:, 400, 1] = qkv[:, 450, 0] * 6.0   # key 400 aligned with query 450 -> huge score late
+    qkv16 = qkv.bfloat16()
+    ref = R.attention_fp32(qkv16[:, :, 0], qkv16[:, :, 1], qkv16[:, :, 2], causal=True)[0]
+    out, _ = run_flash_fixed(qkv16.to(DEV), d ** -0.5, True)
+    assert (out.float().cpu() - ref.float()).abs().max().item() < 3e-2
+
+
+# ---------------------------------------------------------------------------------------------
+# Backpack sense weights and fused mix
+# ---------------------------------------------------------------------------------------------
+def _qk_from_golden(g, tag):
+    w, bias, h = from_bits16(g[f'{tag}_w']), from_bits16(g[f'{tag}_b']), from_bits16(g[f'{tag}_h'])
+    k = int(g[f'{tag}_k'])
+    b, s, d = h.shape
+    qk32 = torch.nn.functional.linear(h, w, bias).reshape(b, s, 2, k, d // k)
+    return qk32, k
+
+
+@pytest.mark.parametrize('tag', ['dk24', 'dk48', 'dk40', 'dk10'])
+def test_sense_alpha_golden(tag):
+    """G1: alpha of the reference's ContextSelfAttn; zeros above the diagonal bit-exact."""
+    bp = _bp()
+    g = load_golden('g12_sense.npz')
+    qk32, k = _qk_from_golden(g, tag)
+    qk16 = qk32.bfloat16()
+    want = R.sense_alpha_from_qk(qk16.float())          # fp32 oracle on the 16-bit inputs
+    eager = R.sense_alpha_from_qk(qk16)                 # reference op order in bf16
+    alpha = bp.sense_alpha(qk16.to(DEV))
+    rel_check(alpha, want, eager, f'alpha {tag}', atol=4e-3)
+    s = alpha.shape[-1]
+    upper = torch.triu(torch.ones(s, s, dtype=torch.bool), 1)
+    assert torch.count_nonzero(alpha.cpu()[:, :, upper]) == 0
+    # and against the stored reference output (fp32 inputs -> looser: input rounding of qk)
+    assert (alpha.float().cpu() - torch.from_numpy(g[f'{tag}_alpha'])).abs().max().item() < 0.05
+
+
+@pytest.mark.parametrize('tag', ['dk24', 'dk48', 'dk40', 'dk10'])
+def test_sense_mix_golden(tag):
+    """G2: fused mix vs sum(alpha @ C) of the reference."""
+    bp = _bp()
+    g = load_golden('g12_sense.npz')
+    qk32, k = _qk_from_golden(g, tag)
+    qk16 = qk32.bfloat16()
+    content = from_bits16(g[f'{tag}_content'])           # (B,S,k,dout) storage layout
+    c16 = content.bfloat16()
+    want = R.sense_mix_from_qk_fp32(qk16, c16.transpose(1, 2))
+    eager = R.sense_mix(R.sense_alpha_from_qk(qk16), c16.transpose(1, 2))
+    out = bp.sense_mix(qk16.to(DEV), c16.to(DEV))
+    rel_check(out, want, eager, f'mix {tag}')
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [
+    # (B, S, k, d_k, d_out)
+    (2, 300, 16, 48, 768),     # Small dims, ragged S
+    (1, 1024, 16, 48, 768),    # BASELINE config 2 shape, one sample
+    (2, 257, 64, 10, 640),     # Mini k=64: d_k = 10 (element-wise loader), d_out not a multiple of 256
+    (2, 128, 16, 24, 384),     # Micro
+    (1, 513, 16, 40, 640),     # Mini k=16
+    (2, 64, 4, 16, 100),       # odd d_out (element-wise stores)
+])
+def test_sense_mix_random(shape, dtype):
+    bp = _bp()
+    b, s, k, dk, dout = shape
+    torch.manual_seed(s + dk)
+    qk = (torch.randn(b, s, 2, k, dk) * 1.2).to(dtype)
+    c = torch.randn(b, s, k, dout).to(dtype)
+    want = R.sense_mix_from_qk_fp32(qk, c.transpose(1, 2))
+    eager = R.sense_mix(R.sense_alpha_from_qk(qk), c.transpose(1, 2))
+    out = bp.sense_mix(qk.to(DEV), c.to(DEV))
+    rel_check(out, want, eager, f'mix {shape} {dtype}')
+
+
+def test_sense_mix_strided_views():
+    """qk and content as the model hands them over: slices of bigger buffers."""
+    bp = _bp()
+    torch.manual_seed(9)
+    b, s, k, dk, dout = 2, 200, 16, 48, 768
+    big = torch.randn(b, s + 8, 2 * k * dk + 64).bfloat16().to(DEV)
+    qk = big[:, 4:4 + s, 32:32 + 2 * k * dk].unflatten(-1, (2, k, dk))
+    cbig = torch.randn(b, s, k * dout + 16).bfloat16().to(DEV)
+    c = cbig[:, :, 8:8 + k * dout].unflatten(-1, (k, dout))
+    want = R.sense_mix_from_qk_fp32(qk.cpu(), c.cpu().transpose(1, 2))
+    eager = R.sense_mix(R.sense_alpha_from_qk(qk.cpu()), c.cpu().transpose(1, 2))
+    out = bp.sense_mix(qk, c)
+    rel_check(out, want, eager, 'mix strided')
+
+
+def test_sense_alpha_rows_sum_to_one_full_size():
+    """BASELINE config-2 size: size-independent properties of alpha (row sums, exact zeros)."""
+    bp = _bp()
+    torch.manual_seed(2)
+    qk = torch.randn(2, 1024, 2, 16, 48, device=DEV).bfloat16()
+    alpha = bp.sense_alpha(qk)
+    sums = alpha.float().sum(-1)
+    assert (sums - 1).abs().max().item() < 2e-2
+    upper = torch.triu(torch.ones(1024, 1024, dtype=torch.bool, device=DEV), 1)
+    assert torch.count_nonzero(alpha[:, :, upper]) == 0
+    assert torch.equal(alpha[:, :, 0, 0], torch.ones_like(alpha[:, :, 0, 0]))
+
+
+def test_sense_mix_linearity_full_size():
+    """mix(qk, a*C1 + C2) == a*mix(qk, C1) + mix(qk, C2) up to 16-bit rounding, at full size."""
+    bp = _bp()
+    torch.manual_seed(4)
+    b, s, k, dk, d = 2, 1024, 16, 48, 768
+    qk = torch.randn(b, s, 2, k, dk, device=DEV).bfloat16()
+    c1 = torch.randn(b, s, k, d, device=DEV).bfloat16()
+    c2 = torch.randn(b, s, k, d, device=DEV).bfloat16()
+    o1 = bp.sense_mix(qk, c1).float()
+    o2 = bp.sense_mix(qk, c2).float()
+    o12 = bp.sense_mix(qk, (2 * c1.float() + c2.float()).bfloat16()).float()
+    assert (o12 - (2 * o1 + o2)).abs().max().item() < 0.15
+    # row 0 attends only to itself: out[0] = sum_l C[0, l]
+    want0 = c1[:, 0].float().sum(1)
+    assert (o1[:, 0] - want0).abs().max().item() < 0.1
+
+
+def test_errors_are_loud():
+    bp = _bp()
+    q = torch.randn(64, 2, 64, device=DEV).bfloat16()
+    out = torch.empty_like(q)
+    cu = torch.tensor([0, 64], dtype=torch.int32, device=DEV)
+    with pytest.raises(RuntimeError):
+        bp.flash_fwd(q.float(), q.float(), q.float(), out.float(), cu, cu, 64, 64, 0.125, True)
+    with pytest.raises(RuntimeError):
+        bp.flash_fwd(q, q, q, out, cu, cu, 64, 64, float('nan'), True)
+    big = torch.randn(64, 2, 136, device=DEV).bfloat16()
+    with pytest.raises(RuntimeError):
+        bp.flash_fwd(big, big, big, torch.empty_like(big), cu, cu, 64, 64, 0.1, True)
+    with pytest.raises(RuntimeError):
+        bp.flash_fwd(q.cpu(), q.cpu(), q.cpu(), out.cpu(), cu.cpu(), cu.cpu(), 64, 64, 0.125, True)
