@@ -25,8 +25,9 @@ SIGNATURES = {
     'bp_abi_version': (_i32, []),
     'bp_flash_fwd': (_i32, [_ptr] * 7 + [_i32] * 5 + [_i64] * 9 + [_f32, _i32, _i32, _ptr]),
     'bp_attn_probs': (_i32, [_ptr] * 4 + [_i32] * 5 + [_i64] * 10 + [_f32, _i32, _i32, _ptr]),
-    'bp_sense_alpha': (_i32, [_ptr] * 3 + [_i32] * 4 + [_i64] * 4 + [_f32, _i32, _ptr]),
-    'bp_sense_mix': (_i32, [_ptr] * 4 + [_i32] * 5 + [_i64] * 9 + [_f32, _i32, _ptr]),
+    'bp_sense_lse': (_i32, [_ptr] * 2 + [_i32] * 4 + [_i64] * 4 + [_f32, _i32, _ptr]),
+    'bp_sense_alpha': (_i32, [_ptr] * 3 + [_i32] * 5 + [_i64] * 4 + [_f32, _i32, _ptr]),
+    'bp_sense_mix': (_i32, [_ptr] * 4 + [_i32] * 6 + [_i64] * 9 + [_f32, _i32, _ptr]),
 }
 
 
@@ -154,22 +155,43 @@ def _check_qk(qk):
     return qk.shape[0], qk.shape[1], qk.shape[3], qk.shape[4]
 
 
-def sense_alpha(qk, softmax_scale=None):
+def sense_lse(qk, softmax_scale=None):
+    """qk (B,S,2,k,d_k) -> lse (B,k,roundup(S,16)) fp32: log-sum-exp of every causal row."""
+    b, s, k, dk = _check_qk(qk)
+    scale = softmax_scale or dk ** -0.5
+    lse = torch.empty((b, k, round_up(s, 16)), dtype=torch.float32, device=qk.device)
+    with torch.cuda.device(qk.device):
+        code = lib().bp_sense_lse(qk.data_ptr(), lse.data_ptr(), b, s, k, dk,
+                                  qk.stride(0), qk.stride(1), qk.stride(2), qk.stride(3),
+                                  float(scale), _dtype_code(qk), _stream())
+    _check(code, 'bp_sense_lse')
+    return lse
+
+
+def _lse_ws(qk, lse, b, s, k):
+    if lse is None:
+        return torch.empty((b, k, round_up(s, 16)), dtype=torch.float32, device=qk.device), 0
+    if lse.shape != (b, k, round_up(s, 16)) or lse.dtype != torch.float32 or not lse.is_contiguous():
+        raise RuntimeError('bp_hip: lse must be the tensor returned by sense_lse for this qk')
+    return lse, 1
+
+
+def sense_alpha(qk, softmax_scale=None, lse=None):
     """qk (B,S,2,k,d_k) -> alpha (B,k,S,S), causal softmax over keys, exact zeros above the
-    diagonal (replaces backpack.py:116-122)."""
+    diagonal (replaces backpack.py:116-122).  `lse`: optional result of sense_lse(qk)."""
     b, s, k, dk = _check_qk(qk)
     scale = softmax_scale or dk ** -0.5
     alpha = torch.empty((b, k, s, s), dtype=qk.dtype, device=qk.device)
-    ws = torch.empty((b, k, round_up(s, 16)), dtype=torch.float32, device=qk.device)
+    ws, ready = _lse_ws(qk, lse, b, s, k)
     with torch.cuda.device(qk.device):
-        code = lib().bp_sense_alpha(qk.data_ptr(), alpha.data_ptr(), ws.data_ptr(), b, s, k, dk,
+        code = lib().bp_sense_alpha(qk.data_ptr(), alpha.data_ptr(), ws.data_ptr(), ready, b, s, k, dk,
                                     qk.stride(0), qk.stride(1), qk.stride(2), qk.stride(3),
                                     float(scale), _dtype_code(qk), _stream())
     _check(code, 'bp_sense_alpha')
     return alpha
 
 
-def sense_mix(qk, content, softmax_scale=None, out=None):
+def sense_mix(qk, content, softmax_scale=None, out=None, lse=None):
     """Fused sum_l softmax_causal(q_l k_l^T * scale) @ C_l without materialising alpha.
 
     qk (B,S,2,k,d_k); content in its storage layout (B,S,k,d_out) (the reference's
@@ -185,10 +207,10 @@ def sense_mix(qk, content, softmax_scale=None, out=None):
     scale = softmax_scale or dk ** -0.5
     if out is None:
         out = torch.empty((b, s, dout), dtype=qk.dtype, device=qk.device)
-    ws = torch.empty((b, k, round_up(s, 16)), dtype=torch.float32, device=qk.device)
+    ws, ready = _lse_ws(qk, lse, b, s, k)
     with torch.cuda.device(qk.device):
         code = lib().bp_sense_mix(qk.data_ptr(), content.data_ptr(), out.data_ptr(), ws.data_ptr(),
-                                  b, s, k, dk, dout,
+                                  ready, b, s, k, dk, dout,
                                   qk.stride(0), qk.stride(1), qk.stride(2), qk.stride(3),
                                   content.stride(0), content.stride(1), content.stride(2),
                                   out.stride(0), out.stride(1),

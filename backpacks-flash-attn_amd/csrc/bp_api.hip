@@ -132,7 +132,20 @@ static int sense_lse(const void *qk, float *lse_ws, int batch, int seqlen, int n
     return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
 }
 
-int bp_sense_alpha(const void *qk, void *alpha, float *lse_ws,
+int bp_sense_lse(const void *qk, float *lse, int batch, int seqlen, int nsenses, int d_k,
+                 int64_t qk_batch_stride, int64_t qk_row_stride, int64_t qk_two_stride,
+                 int64_t qk_sense_stride, float softmax_scale, int dtype, bp_stream_t stream) {
+    if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
+    if (d_k < 1 || d_k > 128) return BP_ERR_HEAD_DIM;
+    if (batch <= 0 || nsenses <= 0 || seqlen <= 0) return BP_ERR_SHAPE;
+    if (qk == nullptr || lse == nullptr) return BP_ERR_SHAPE;
+    if (!scale_ok(softmax_scale)) return BP_ERR_SCALE;
+    return sense_lse(qk, lse, batch, seqlen, nsenses, d_k, qk_batch_stride, qk_row_stride,
+                     qk_two_stride, qk_sense_stride, softmax_scale, dtype,
+                     static_cast<hipStream_t>(stream));
+}
+
+int bp_sense_alpha(const void *qk, void *alpha, float *lse_ws, int lse_ready,
                    int batch, int seqlen, int nsenses, int d_k,
                    int64_t qk_batch_stride, int64_t qk_row_stride, int64_t qk_two_stride,
                    int64_t qk_sense_stride, float softmax_scale, int dtype, bp_stream_t stream) {
@@ -142,9 +155,11 @@ int bp_sense_alpha(const void *qk, void *alpha, float *lse_ws,
     if (qk == nullptr || alpha == nullptr || lse_ws == nullptr) return BP_ERR_SHAPE;
     if (!scale_ok(softmax_scale)) return BP_ERR_SCALE;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    int rc = sense_lse(qk, lse_ws, batch, seqlen, nsenses, d_k, qk_batch_stride, qk_row_stride,
-                       qk_two_stride, qk_sense_stride, softmax_scale, dtype, st);
-    if (rc != BP_OK) return rc;
+    if (!lse_ready) {
+        int rc = sense_lse(qk, lse_ws, batch, seqlen, nsenses, d_k, qk_batch_stride, qk_row_stride,
+                           qk_two_stride, qk_sense_stride, softmax_scale, dtype, st);
+        if (rc != BP_OK) return rc;
+    }
     const uint16_t *qp = static_cast<const uint16_t *>(qk);
     const int64_t S = seqlen;
     return bp_attn_probs(qp, qp + qk_two_stride, lse_ws, alpha, batch, nsenses, d_k, seqlen, seqlen,
@@ -155,7 +170,7 @@ int bp_sense_alpha(const void *qk, void *alpha, float *lse_ws,
                          softmax_scale, 1, dtype, stream);
 }
 
-int bp_sense_mix(const void *qk, const void *content, void *out, float *lse_ws,
+int bp_sense_mix(const void *qk, const void *content, void *out, float *lse_ws, int lse_ready,
                  int batch, int seqlen, int nsenses, int d_k, int d_out,
                  int64_t qk_batch_stride, int64_t qk_row_stride, int64_t qk_two_stride,
                  int64_t qk_sense_stride,
@@ -169,9 +184,11 @@ int bp_sense_mix(const void *qk, const void *content, void *out, float *lse_ws,
     if (qk == nullptr || content == nullptr || out == nullptr || lse_ws == nullptr) return BP_ERR_SHAPE;
     if (!scale_ok(softmax_scale)) return BP_ERR_SCALE;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    int rc = sense_lse(qk, lse_ws, batch, seqlen, nsenses, d_k, qk_batch_stride, qk_row_stride,
-                       qk_two_stride, qk_sense_stride, softmax_scale, dtype, st);
-    if (rc != BP_OK) return rc;
+    if (!lse_ready) {
+        int rc = sense_lse(qk, lse_ws, batch, seqlen, nsenses, d_k, qk_batch_stride, qk_row_stride,
+                           qk_two_stride, qk_sense_stride, softmax_scale, dtype, st);
+        if (rc != BP_OK) return rc;
+    }
 
     const uint16_t *qp = static_cast<const uint16_t *>(qk);
     bp::MixParams p{};

@@ -1,0 +1,277 @@
+"""Headline benchmark: forward tokens/s of Backpack-Small (d=768, 12 heads, 12 layers, k=16 senses)
+at seq 1024, bf16, on N MI355X (BASELINE.json `metric`), plus the roofline fraction of the
+dominant HIP kernel and the CPU-eager baseline timed in the same run.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workload NAME]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full forward (ids -> logits) over one batch of synthetic token ids already resident
+in HBM; weights are random with the reference's init scheme (no network for checkpoints).
+The forward shards by batch with no data-path collective: N ranks = N independent replicas
+(weak scaling), value = all ranks' tokens / max-over-ranks time.
+
+Per-kernel durations are measured live with HIP events (torch.cuda.Event on the stream the kernels
+are launched on = torch's current stream) around every launch inside the timed region.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, 'backpacks-flash-attn_amd')
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+# MI355X peaks from /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
+PEAK_MFMA_TFLOPS = 2500.0   # dense bf16/fp16 MFMA
+PEAK_HBM_GBPS = 8000.0      # HBM3E
+
+WORKLOADS = {
+    # name: (model, seq, dtype, default batch)  -- BASELINE.json configs[1] is the headline
+    'small-1024': ('small', 1024, 'bf16', 64),
+    'small-4096-fp16': ('small', 4096, 'fp16', 8),
+    'mini-k64-1024': ('mini-k64', 1024, 'bf16', 32),
+    'micro-128': ('micro', 128, 'bf16', 4),
+}
+MODELS = {
+    'micro': dict(n_embd=384, n_head=6, n_layer=6, num_content_vectors=16),
+    'mini-k64': dict(n_embd=640, n_head=8, n_layer=8, num_content_vectors=64, shrink_final_inner=True),
+    'small': dict(n_embd=768, n_head=12, n_layer=12, num_content_vectors=16),
+}
+
+
+class KernelClock:
+    """HIP-event stopwatch around individual kernel launches."""
+
+    def __init__(self):
+        self.enabled = False
+        self.spans = {}
+
+    def wrap(self, name, fn):
+        def timed(*a, **kw):
+            if not self.enabled:
+                return fn(*a, **kw)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **kw)
+            e1.record()
+            self.spans.setdefault(name, []).append((e0, e1))
+            return out
+        return timed
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, spans in self.spans.items():
+            ms = [a.elapsed_time(b) for a, b in spans]
+            out[name] = dict(launches=len(ms), avg_ms=sum(ms) / len(ms), total_ms=sum(ms))
+        return out
+
+
+def instrument(clock):
+    """Bracket each HIP kernel launch with events.  The fused sense mix is split into its two
+    launches (LSE pre-pass, mix) through the public lse= argument so each kernel is timed alone."""
+    import bp_hip
+    raw_flash, raw_lse, raw_mix = bp_hip.flash_fwd, bp_hip.sense_lse, bp_hip.sense_mix
+    t_flash = clock.wrap('flash_fwd_kernel', raw_flash)
+    t_lse = clock.wrap('flash_fwd_kernel[lse-only,senses]', raw_lse)
+    t_mix = clock.wrap('sense_mix_kernel', raw_mix)
+
+    def mix_two_launches(qk, content, softmax_scale=None, out=None, lse=None):
+        if lse is None:
+            lse = t_lse(qk, softmax_scale)
+        return t_mix(qk, content, softmax_scale, out=out, lse=lse)
+
+    bp_hip.flash_fwd = t_flash
+    bp_hip.sense_mix = mix_two_launches
+
+
+def build_model(name, seq, dtype, device):
+    from src.models.backpack import BackpackConfig, BackpackLMHeadModel
+    cfg = BackpackConfig(vocab_size=50257, n_positions=seq, scale_attn_by_inverse_layer_idx=True,
+                         use_flash_attn=True, fused_bias_fc=True, fused_dense_gelu_dense=True,
+                         fused_dropout_add_ln=True, pad_vocab_size_multiple=8, **MODELS[name])
+    torch.manual_seed(0)
+    model = BackpackLMHeadModel(cfg, device=device, dtype=dtype).eval()
+    return cfg, model
+
+
+def algorithmic_work(cfg, batch, seq):
+    """SURVEY.md section 8(d) per-sample figures x batch.  2-byte elements, causal pairs only."""
+    d, h, L, k = cfg.n_embd, cfg.n_head, cfg.n_layer, cfg.num_content_vectors
+    pairs = seq * (seq + 1) // 2
+    return {
+        # one trunk layer = one launch: 4*pairs*d flops, q,k,v read + o written = 8*S*d bytes
+        'flash_fwd_kernel': dict(flops=4 * pairs * d * batch, bytes=8 * seq * d * batch),
+        # fused mix launch: QK^T once + alpha.C ; reads qk (4*S*d) + C (2*k*S*d), writes out (2*S*d)
+        'sense_mix_kernel': dict(flops=2 * pairs * d * (1 + k) * batch,
+                                 bytes=(4 + 2 * k + 2) * seq * d * batch),
+        # LSE pre-pass: QK^T once, reads qk, writes k*S fp32
+        'flash_fwd_kernel[lse-only,senses]': dict(flops=2 * pairs * d * batch,
+                                                  bytes=(4 * seq * d + 4 * k * seq) * batch),
+    }
+
+
+def cpu_baseline(model_name, seq, budget_s=15.0):
+    """The reference's eager CPU path (restated in oracle/ref_cpu.py, validated against the real
+    reference by tests/golden/make_golden.py) on this host's cores: fp32, all threads."""
+    from oracle import ref_cpu as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = R.make_config(model_name, n_positions=seq)
+    sd = R.init_state_dict(cfg, seed=0)
+    b = 1
+    ids = torch.randint(0, 50257, (b, seq), generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        R.backpack_forward(sd, cfg, ids)  # warm-up
+        times = []
+        t_start = time.perf_counter()
+        while len(times) < 3 or (time.perf_counter() - t_start < budget_s and len(times) < 50):
+            t0 = time.perf_counter()
+            R.backpack_forward(sd, cfg, ids)
+            times.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_start > 2 * budget_s:
+                break
+    mean = sum(times) / len(times)
+    return dict(value=b * seq / mean, unit='tokens/s', cores=cores, kind='port',
+                sample=f'oracle/ref_cpu.backpack_forward (reference eager path), Backpack-{model_name} '
+                       f'fp32, batch {b} x seq {seq}, {len(times)} timed forwards after 1 warm-up, '
+                       f'mean {mean:.3f} s/forward, torch {torch.get_num_threads()} threads')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=None, help='samples per GPU per step')
+    ap.add_argument('--workload', default='small-1024', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-events', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=device)   # 'nccl' is RCCL on ROCm
+
+    import bp_hip
+    bp_hip.lib()   # fail loudly if the HIP extension is missing -- no fallback path exists
+
+    model_name, seq, dtype_name, default_batch = WORKLOADS[args.workload]
+    dtype = torch.bfloat16 if dtype_name == 'bf16' else torch.float16
+    batch = args.batch or default_batch
+    cfg, model = build_model(model_name, seq, dtype, device)
+    ids = torch.randint(0, 50257, (batch, seq), device=device,
+                        generator=torch.Generator(device=device).manual_seed(1234 + rank))
+
+    clock = KernelClock()
+    if not args.no_kernel_events:
+        instrument(clock)
+
+    def step():
+        with torch.no_grad():
+            return model(ids).logits
+
+    for _ in range(args.warmup):
+        out = step()
+    del out
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    clock.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    clock.enabled = False
+    assert out.shape == (batch, seq, cfg.vocab_size) and bool(torch.isfinite(out[0, -1].float()).all())
+
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernels = clock.summary()
+    work = algorithmic_work(cfg, batch, seq)
+    kernel_rows = []
+    for name, k in kernels.items():
+        w = work[name]
+        sec = k['avg_ms'] * 1e-3
+        tf = w['flops'] / sec / 1e12
+        gbs = w['bytes'] / sec / 1e9
+        kernel_rows.append(dict(kernel=name, launches_per_step=k['launches'] // max(args.steps, 1),
+                                avg_ms=round(k['avg_ms'], 4), total_ms=round(k['total_ms'], 3),
+                                algorithmic_flops=w['flops'], algorithmic_bytes=w['bytes'],
+                                tflops=round(tf, 1), mfma_frac=round(tf / PEAK_MFMA_TFLOPS, 4),
+                                gbps=round(gbs, 1), hbm_frac=round(gbs / PEAK_HBM_GBPS, 4)))
+    kernel_rows.sort(key=lambda r: -r['total_ms'])
+
+    if rank == 0:
+        tokens = world * batch * seq * args.steps
+        line = {
+            'metric': 'tokens/sec fwd, Backpack-Small seq=1024' if args.workload == 'small-1024'
+                      else f'tokens/sec fwd, {args.workload}',
+            'value': round(tokens / elapsed, 1),
+            'unit': 'tokens/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': dtype_name,
+            'data': 'synthetic token ids, random weights (reference init scheme)',
+            'config': {'workload': f'Backpack-{model_name} forward (ids -> logits), d={cfg.n_embd}, '
+                                   f'{cfg.n_head} heads, {cfg.n_layer} layers, k={cfg.num_content_vectors} '
+                                   f'senses, vocab {cfg.vocab_size}, seq {seq}',
+                       'batch_per_gpu': batch, 'global_batch': batch * world, 'seq_len': seq,
+                       'parallelism': f'{world} independent batch replicas (no data-path collective)'},
+        }
+        if kernel_rows:
+            dom = kernel_rows[0]
+            traffic = None
+            tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(f"{args.workload}/b{batch}/{dom['kernel']}")
+                except Exception:
+                    traffic = None
+            line['roofline'] = {'kernel': dom['kernel'], 'bound': 'mfma',
+                                'achieved': dom['tflops'], 'peak': PEAK_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                'frac': dom['mfma_frac'], 'traffic': traffic,
+                                'avg_launch_ms': dom['avg_ms'], 'hbm_gbps': dom['gbps'],
+                                'hbm_frac': dom['hbm_frac']}
+            line['kernels'] = kernel_rows
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(model_name, seq)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -85,6 +85,18 @@ int bp_attn_probs(const void *q, const void *k, const float *softmax_lse, void *
                   float softmax_scale, int is_causal, int dtype, bp_stream_t stream);
 
 /*
+ * bp_sense_lse -- log-sum-exp of every (sense, query) row of the causal sense attention:
+ *   lse[b,l,t] = log sum_{s<=t} exp(scale * q_l[t].k_l[s])
+ * First pass of bp_sense_alpha / bp_sense_mix, exported so callers can share one LSE between them
+ * (and time the passes separately).  The reference computes this inside torch.softmax
+ * (training/src/models/backpack.py:122).
+ *   lse (batch, nsenses, roundup(seqlen,16)) fp32, natural log.
+ */
+int bp_sense_lse(const void *qk, float *lse, int batch, int seqlen, int nsenses, int d_k,
+                 int64_t qk_batch_stride, int64_t qk_row_stride, int64_t qk_two_stride,
+                 int64_t qk_sense_stride, float softmax_scale, int dtype, bp_stream_t stream);
+
+/*
  * bp_sense_alpha -- Backpack contextualisation weights
  *   alpha[b,l,t,s] = softmax_s( q_l[t].k_l[s] * scale ) over s <= t, 0 for s > t.
  * Replaces the eager body of ContextSelfAttn.forward after its Wqkv projection
@@ -93,8 +105,9 @@ int bp_attn_probs(const void *q, const void *k, const float *softmax_lse, void *
  *          element strides qk_batch/qk_row/qk_two/qk_sense, last stride 1
  *   alpha  (batch, nsenses, seqlen, seqlen) 16-bit contiguous, caller-allocated
  *   lse_ws fp32 scratch, batch * nsenses * roundup(seqlen,16) elements
+ *   lse_ready  0: compute the LSE into lse_ws first;  1: lse_ws already holds bp_sense_lse's result
  */
-int bp_sense_alpha(const void *qk, void *alpha, float *lse_ws,
+int bp_sense_alpha(const void *qk, void *alpha, float *lse_ws, int lse_ready,
                    int batch, int seqlen, int nsenses, int d_k,
                    int64_t qk_batch_stride, int64_t qk_row_stride, int64_t qk_two_stride,
                    int64_t qk_sense_stride, float softmax_scale, int dtype, bp_stream_t stream);
@@ -110,8 +123,9 @@ int bp_sense_alpha(const void *qk, void *alpha, float *lse_ws,
  *            c_batch/c_row/c_sense, last stride 1.  d_out is free (vocab-sized content works).
  *   out      (batch, seqlen, d_out) 16-bit, strides o_batch/o_row
  *   lse_ws   fp32 scratch, batch * nsenses * roundup(seqlen,16) elements
+ *   lse_ready  as in bp_sense_alpha
  */
-int bp_sense_mix(const void *qk, const void *content, void *out, float *lse_ws,
+int bp_sense_mix(const void *qk, const void *content, void *out, float *lse_ws, int lse_ready,
                  int batch, int seqlen, int nsenses, int d_k, int d_out,
                  int64_t qk_batch_stride, int64_t qk_row_stride, int64_t qk_two_stride,
                  int64_t qk_sense_stride,

@@ -1,0 +1,147 @@
+"""-m gpu: the reference's Python call sites running on the HIP kernels, against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import from_bits16, load_golden
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _nano(use_flash=True, dtype=torch.bfloat16):
+    from src.models.backpack import BackpackConfig, BackpackLMHeadModel
+    g = load_golden('g4_nano_model.npz')
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd/')}
+    cfg = BackpackConfig(n_embd=64, n_head=2, n_layer=2, num_content_vectors=4, vocab_size=96,
+                         n_positions=32, scale_attn_by_inverse_layer_idx=True, resid_pdrop=0.0,
+                         embd_pdrop=0.0, attn_pdrop=0.0, use_flash_attn=use_flash,
+                         pad_vocab_size_multiple=8)
+    model = BackpackLMHeadModel(cfg)
+    model.load_state_dict(sd)
+    return g, sd, model.to(DEV, dtype).eval()
+
+
+def test_nano_model_hip_vs_golden():
+    g, sd, model = _nano()
+    ids = torch.from_numpy(g['ids']).to(DEV)
+    with torch.no_grad():
+        t = model.transformer
+        h = t.gpt2_model(ids)
+        alpha = t.contextualization_attn(h)          # bp_sense_alpha
+        hidden = t(ids)                              # flash trunk + fused mix
+        logits = model(ids).logits
+    ocfg = dict(n_embd=64, n_head=2, n_layer=2, num_content_vectors=4,
+                layer_norm_epsilon=float(g['layer_norm_epsilon']), scale_attn_by_inverse_layer_idx=True)
+    sd16 = {k: v.bfloat16() for k, v in sd.items()}
+    eager = R.backpack_forward(sd16, ocfg, torch.from_numpy(g['ids']), return_stages=True)
+    for got, name in ((h, 'trunk'), (alpha, 'alpha'), (hidden, 'hidden'), (logits, 'logits')):
+        want = torch.from_numpy(g[name])
+        err = (got.float().cpu() - want).abs().max().item()
+        base = (eager[name].float() - want).abs().max().item()
+        print(f'{name}: hip {err:.3e} eager-bf16 {base:.3e}')
+        assert err <= 3 * base + 1e-3, (name, err, base)
+    s = alpha.shape[-1]
+    upper = torch.triu(torch.ones(s, s, dtype=torch.bool, device=DEV), 1)
+    assert torch.count_nonzero(alpha[:, :, upper]) == 0
+
+
+def test_fused_path_equals_materialised_alpha_path():
+    """BackpackModel.forward (fused, alpha never stored) vs alpha from ContextSelfAttn @ content."""
+    g, sd, model = _nano()
+    ids = torch.from_numpy(g['ids']).to(DEV)
+    with torch.no_grad():
+        t = model.transformer
+        h = t.gpt2_model(ids)
+        alpha = t.contextualization_attn(h)
+        content = t.content_model(ids)
+        two_step = torch.sum(alpha.float() @ content.float(), dim=1)
+        fused = t(ids).float()
+    assert (fused - two_step).abs().max().item() < 3e-2
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_micro_config1_forward(dtype):
+    """BASELINE config 1 shape (Backpack-Micro, B=4, S=128): HIP 16-bit vs the fp32 CPU oracle."""
+    from src.models.backpack import BackpackConfig, BackpackLMHeadModel
+    cfg = BackpackConfig(n_embd=384, n_head=6, n_layer=6, num_content_vectors=16, vocab_size=50257,
+                         n_positions=128, scale_attn_by_inverse_layer_idx=True, resid_pdrop=0.0,
+                         embd_pdrop=0.0, attn_pdrop=0.0, use_flash_attn=True, pad_vocab_size_multiple=8)
+    torch.manual_seed(0)
+    model = BackpackLMHeadModel(cfg).eval()
+    with torch.no_grad():   # sharpen attention so the softmax paths matter
+        model.transformer.contextualization_attn.Wqkv.weight.mul_(8.0)
+        for layer in model.transformer.gpt2_model.layers:
+            layer.mixer.Wqkv.weight.mul_(6.0)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ids = torch.randint(0, 50257, (4, 128), generator=torch.Generator().manual_seed(0))
+    ocfg = dict(n_embd=384, n_head=6, n_layer=6, num_content_vectors=16, layer_norm_epsilon=1e-5,
+                scale_attn_by_inverse_layer_idx=True)
+    want = R.backpack_forward(sd, ocfg, ids, return_stages=True)
+    sd16 = {k: v.to(dtype) for k, v in sd.items()}
+    eager = R.backpack_forward(sd16, ocfg, ids, return_stages=True)
+    model = model.to(DEV, dtype)
+    with torch.no_grad():
+        hidden = model.transformer(ids.to(DEV))
+        logits = model(ids.to(DEV)).logits
+    for got, name in ((hidden, 'hidden'), (logits, 'logits')):
+        err = (got.float().cpu() - want[name]).abs().max().item()
+        base = (eager[name].float() - want[name]).abs().max().item()
+        print(f'micro {dtype} {name}: hip {err:.3e} eager {base:.3e}')
+        assert err <= 3 * base + 1e-3, (name, err, base)
+
+
+def test_interface_functions_and_probs():
+    from flash_attn.flash_attn_interface import (flash_attn_unpadded_func,
+                                                 flash_attn_unpadded_kvpacked_func,
+                                                 flash_attn_unpadded_qkvpacked_func)
+    torch.manual_seed(0)
+    b, s, h, d = 2, 160, 4, 64
+    qkv = torch.randn(b, s, 3, h, d).bfloat16()
+    cu = torch.arange(0, (b + 1) * s, s, dtype=torch.int32, device=DEV)
+    flat = qkv.flatten(0, 1).to(DEV)
+    for causal in (False, True):
+        want, attn, lse_want = R.attention_fp32(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], causal=causal)
+        out, lse, probs = flash_attn_unpadded_qkvpacked_func(flat, cu, s, 0.0, causal=causal,
+                                                             return_attn_probs=True)
+        assert out.shape == (b * s, h, d) and lse.shape == (b, h, 160) and probs.shape == (b, h, s, s)
+        assert (out.float().cpu().unflatten(0, (b, s)) - want.float()).abs().max().item() < 2e-2
+        assert (probs.float().cpu() - attn.float()).abs().max().item() < 1e-2
+        assert (lse.cpu() - lse_want).abs().max().item() < 2e-3
+        out2 = flash_attn_unpadded_kvpacked_func(flat[:, 0], flat[:, 1:], cu, cu, s, s, 0.0, causal=causal)
+        out3 = flash_attn_unpadded_func(flat[:, 0], flat[:, 1], flat[:, 2], cu, cu, s, s, 0.0, causal=causal)
+        assert torch.equal(out, out2) and torch.equal(out, out3)
+
+
+def test_flash_attention_module_with_padding_mask():
+    from flash_attn.flash_attention import FlashAttention
+    from flash_attn.modules.mha import FlashSelfAttention, SelfAttention
+    torch.manual_seed(1)
+    b, s, h, d = 3, 96, 2, 64
+    qkv = torch.randn(b, s, 3, h, d).bfloat16()
+    lens = torch.tensor([96, 40, 77])
+    mask = torch.arange(s)[None, :] < lens[:, None]
+    out, none = FlashAttention()(qkv.to(DEV), key_padding_mask=mask.to(DEV), causal=True)
+    assert none is None
+    want = R.attention_fp32(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], causal=True,
+                            query_padding_mask=mask, key_padding_mask=mask)[0]
+    assert (out.float().cpu() - want.float()).abs().max().item() < 2e-2
+    assert torch.count_nonzero(out[1, 40:]) == 0            # padded rows come back as zeros
+    fsa = FlashSelfAttention(causal=True, softmax_scale=0.05)(qkv.to(DEV))
+    eager = SelfAttention(causal=True, softmax_scale=0.05)(qkv.float())
+    assert (fsa.float().cpu() - eager).abs().max().item() < 2e-2
+
+
+def test_autograd_through_the_forward_kernel():
+    """Backward is eager recomputation (FA backward kernels are a 'next' row): gradients must match
+    autograd through the eager twin."""
+    from flash_attn.modules.mha import FlashSelfAttention, SelfAttention
+    torch.manual_seed(2)
+    qkv = (torch.randn(2, 64, 3, 2, 32) * 0.7).bfloat16().to(DEV).requires_grad_()
+    out = FlashSelfAttention(causal=True)(qkv)
+    g = torch.randn_like(out)
+    (dqkv,) = torch.autograd.grad(out, qkv, g)
+    ref_in = qkv.detach().float().requires_grad_()
+    (dref,) = torch.autograd.grad(SelfAttention(causal=True)(ref_in), ref_in, g.float())
+    assert (dqkv.float() - dref).abs().max().item() < 5e-2

@@ -1,0 +1,153 @@
+"""CPU: the drop-in Python call sites (same names / signatures / state-dict keys as the reference)
+running their eager branch (`use_flash_attn=False`, the reference's non-optimised mode), checked
+against the golden vectors; plus padding helpers and the loud-failure rules of the HIP branch."""
+import inspect
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import from_bits16, load_golden
+from oracle import ref_cpu as R
+
+from flash_attn import flash_attn_interface as fai
+from flash_attn.bert_padding import pad_input, unpad_input
+from flash_attn.flash_attention import FlashAttention, FlashMHA
+from flash_attn.modules.mha import MHA, CrossAttention, FlashSelfAttention, SelfAttention
+from src.models.backpack import (BackpackConfig, BackpackLMHeadModel, BackpackModel,
+                                 ContextSelfAttn)
+
+
+def nano_config(**kw):
+    base = dict(n_embd=64, n_head=2, n_layer=2, num_content_vectors=4, vocab_size=96, n_positions=32,
+                scale_attn_by_inverse_layer_idx=True, resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0,
+                pad_vocab_size_multiple=8)
+    base.update(kw)
+    return BackpackConfig(**base)
+
+
+def test_backpack_lm_matches_reference_golden_on_cpu():
+    g = load_golden('g4_nano_model.npz')
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd/')}
+    model = BackpackLMHeadModel(nano_config()).eval()
+    missing, unexpected = model.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected             # reference checkpoints load key-for-key
+    ids = torch.from_numpy(g['ids'])
+    with torch.no_grad():
+        t = model.transformer
+        h = t.gpt2_model(ids)
+        alpha = t.contextualization_attn(h)
+        content = t.content_model(ids)
+        hidden = t(ids)
+        out = model(ids)
+    assert hasattr(out, 'logits') and type(out).__name__ == 'CausalLMOutput'
+    for got, name in ((h, 'trunk'), (alpha, 'alpha'), (content, 'content'), (hidden, 'hidden'),
+                      (out.logits, 'logits')):
+        assert (got - torch.from_numpy(g[name])).abs().max().item() < 2e-5, name
+    # layout contract of the fused kernel: content is a VIEW of a contiguous (B,S,k*d) buffer
+    assert content.shape == (2, 4, 32, 64) and not content.is_contiguous()
+    assert content.transpose(1, 2).is_contiguous()
+    assert model.lm_head.weight is model.transformer.embeddings.word_embeddings.weight
+    assert model.transformer.content_model.embeddings is model.transformer.gpt2_model.embeddings
+
+
+def test_attribute_surface_used_by_the_intervention_scripts():
+    # training/src/models/intervened_models.py:77-101 reaches into these attributes
+    m = BackpackModel(nano_config())
+    for name in ('gpt2_model', 'content_model', 'contextualization_attn', 'embeddings',
+                 'num_content_vectors'):
+        assert hasattr(m, name)
+    assert m.config.vocab_size == 96
+    cfg = nano_config(vocab_size=50257)
+    BackpackModel(cfg)
+    assert cfg.vocab_size == 50264                     # padded to a multiple of 8 (backpack.py:285-288)
+
+
+def test_context_self_attn_matches_golden():
+    g = load_golden('g12_sense.npz')
+    for tag in ('dk24', 'dk40', 'dk10'):
+        k = int(g[f'{tag}_k'])
+        h = from_bits16(g[f'{tag}_h'])
+        mod = ContextSelfAttn(k, h.shape[-1])
+        mod.load_state_dict({'Wqkv.weight': from_bits16(g[f'{tag}_w']), 'Wqkv.bias': from_bits16(g[f'{tag}_b'])})
+        with torch.no_grad():
+            alpha = mod(h)
+        assert (alpha - torch.from_numpy(g[f'{tag}_alpha'])).abs().max().item() < 1e-6
+        assert mod.project(h).shape == (h.shape[0], h.shape[1], 2, k, h.shape[-1] // k)
+
+
+def test_eager_attention_twins_match_golden():
+    g = load_golden('g3_trunk_attn.npz')
+    qkv = from_bits16(g['h64_qkv'])
+    for layer in (0, 5, 11):
+        mod = SelfAttention(causal=True, softmax_scale=64 ** -0.5 / (layer + 1))
+        assert (mod(qkv) - torch.from_numpy(g[f'h64_L{layer}_out'])).abs().max().item() < 1e-6
+    kpm = torch.from_numpy(g['h64_kpm'])
+    out = SelfAttention()(qkv, key_padding_mask=kpm)
+    assert (out - torch.from_numpy(g['h64_kpm_out'])).abs().max().item() < 1e-6
+    cross = CrossAttention(causal=True)(qkv[:, :, 0], qkv[:, :, 1:])
+    assert (cross - SelfAttention(causal=True)(qkv)).abs().max().item() < 1e-6
+
+
+def test_mha_eager_and_per_layer_scale():
+    from flash_attn.models.gpt import create_mixer_cls
+    cfg = nano_config()
+    mixers = [create_mixer_cls(cfg, layer_idx=i)(cfg.hidden_size) for i in range(3)]
+    for i, m in enumerate(mixers):
+        assert isinstance(m, MHA) and m.causal
+        assert abs(m.inner_attn.softmax_scale - 32 ** -0.5 / (i + 1)) < 1e-12   # gpt.py:47-50
+    x = torch.randn(2, 16, 64)
+    y = mixers[1](x)
+    qkv = mixers[1].Wqkv(x).reshape(2, 16, 3, 2, 32)
+    ref = R.self_attention_eager(qkv, True, 32 ** -0.5 / 2)
+    assert (y - mixers[1].out_proj(ref.reshape(2, 16, 64))).abs().max().item() < 1e-6
+
+
+def test_unpad_pad_roundtrip_and_cu_seqlens():
+    g = load_golden('g5_varlen.npz')
+    lens = torch.from_numpy(g['lens'])
+    smax = 128
+    mask = torch.arange(smax)[None, :] < lens[:, None]
+    x = torch.randn(4, smax, 24)
+    rows, idx, cu, max_s = unpad_input(x, mask)
+    assert cu.dtype == torch.int32 and torch.equal(cu, torch.from_numpy(g['cu_seqlens']))
+    assert torch.equal(idx, torch.from_numpy(g['indices'])) and max_s == int(g['max_s'])
+    back = pad_input(rows, idx, 4, smax)
+    assert torch.equal(back, x * mask[:, :, None])
+
+
+def test_public_signatures_match_the_reference():
+    # flash_attn/flash_attn_interface.py:242-380
+    assert list(inspect.signature(fai.flash_attn_unpadded_qkvpacked_func).parameters) == [
+        'qkv', 'cu_seqlens', 'max_seqlen', 'dropout_p', 'softmax_scale', 'causal', 'return_attn_probs']
+    assert list(inspect.signature(fai.flash_attn_unpadded_kvpacked_func).parameters) == [
+        'q', 'kv', 'cu_seqlens_q', 'cu_seqlens_k', 'max_seqlen_q', 'max_seqlen_k', 'dropout_p',
+        'softmax_scale', 'causal', 'return_attn_probs']
+    assert list(inspect.signature(fai.flash_attn_unpadded_func).parameters) == [
+        'q', 'k', 'v', 'cu_seqlens_q', 'cu_seqlens_k', 'max_seqlen_q', 'max_seqlen_k', 'dropout_p',
+        'softmax_scale', 'causal', 'return_attn_probs']
+    assert list(inspect.signature(fai.flash_attn_func).parameters) == [
+        'qkv', 'cu_seqlens', 'dropout_p', 'max_s', 'softmax_scale', 'causal', 'return_attn_probs']
+    assert list(inspect.signature(FlashAttention.forward).parameters) == [
+        'self', 'qkv', 'key_padding_mask', 'causal', 'cu_seqlens', 'max_s', 'need_weights']
+    assert list(inspect.signature(FlashSelfAttention.forward).parameters) == [
+        'self', 'qkv', 'causal', 'cu_seqlens', 'max_seqlen']
+    assert list(inspect.signature(ContextSelfAttn.__init__).parameters)[:3] == [
+        'self', 'num_content_vectors', 'embed_dim']
+
+
+def test_hip_branch_never_falls_back():
+    # 16-bit CUDA tensors are required; CPU input must raise, not silently run eager code
+    qkv = torch.randn(1, 8, 3, 2, 32).bfloat16()
+    with pytest.raises(AssertionError):
+        FlashSelfAttention(causal=True)(qkv)
+    with pytest.raises(AssertionError):
+        FlashAttention()(qkv)
+    model = BackpackLMHeadModel(nano_config(use_flash_attn=True)).eval()
+    assert model.transformer.use_hip and model.transformer.contextualization_attn.use_hip
+    with pytest.raises((AssertionError, RuntimeError)):
+        model(torch.zeros(1, 8, dtype=torch.long))
+    with pytest.raises(RuntimeError, match='dropout'):
+        fai._flash_attn_forward(qkv[0, :, 0], qkv[0, :, 1], qkv[0, :, 2], qkv[0, :, 0].clone(),
+                                None, None, 8, 8, 0.1, 0.2, True, False)
+    assert FlashMHA(64, 2).head_dim == 32
