@@ -1,0 +1,84 @@
+"""Micro-benchmark of the individual HIP kernels on synthetic N(0,1) data (never zeros: zero-filled
+inputs clock higher and flatter -- cdna_hip_programming.md section 5.4 rule 25).
+
+    python scripts/bench_kernels.py [--which flash,mix,lse,alpha] [--batch 64] [--seq 1024] [--iters 20]
+Prints one JSON line per kernel with avg ms, algorithmic TFLOP/s and GB/s (SURVEY section 8d figures)."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'backpacks-flash-attn_amd')):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+
+import bp_hip  # noqa: E402
+
+
+def timeit(fn, iters, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--which', default='flash,mix,lse,alpha')
+    ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--seq', type=int, default=1024)
+    ap.add_argument('--heads', type=int, default=12)
+    ap.add_argument('--headdim', type=int, default=64)
+    ap.add_argument('--senses', type=int, default=16)
+    ap.add_argument('--d', type=int, default=768)
+    ap.add_argument('--dtype', default='bf16')
+    ap.add_argument('--iters', type=int, default=20)
+    a = ap.parse_args()
+    dt = torch.bfloat16 if a.dtype == 'bf16' else torch.float16
+    dev = 'cuda'
+    B, S, H, D, K, d = a.batch, a.seq, a.heads, a.headdim, a.senses, a.d
+    pairs = S * (S + 1) // 2
+    torch.manual_seed(0)
+    which = a.which.split(',')
+    res = []
+    if 'flash' in which:
+        qkv = torch.randn(B * S, 3, H, D, device=dev).to(dt)
+        out = torch.empty_like(qkv[:, 0])
+        cu = torch.arange(0, (B + 1) * S, S, dtype=torch.int32, device=dev)
+        ms = timeit(lambda: bp_hip.flash_fwd(qkv[:, 0], qkv[:, 1], qkv[:, 2], out, cu, cu, S, S, D ** -0.5, True), a.iters)
+        fl, by = 4 * pairs * D * H * B, 8 * S * D * H * B
+        res.append(dict(kernel='flash_fwd', ms=ms, tflops=fl / ms / 1e9, gbps=by / ms / 1e6))
+    if 'lse' in which or 'mix' in which or 'alpha' in which:
+        qk = torch.randn(B, S, 2, K, d // K, device=dev).to(dt)
+    if 'lse' in which:
+        ms = timeit(lambda: bp_hip.sense_lse(qk), a.iters)
+        res.append(dict(kernel='sense_lse', ms=ms, tflops=2 * pairs * d * B / ms / 1e9,
+                        gbps=(4 * S * d + 4 * K * S) * B / ms / 1e6))
+    if 'mix' in which:
+        c = torch.randn(B, S, K, d, device=dev).to(dt)
+        lse = bp_hip.sense_lse(qk)
+        out = torch.empty(B, S, d, device=dev, dtype=dt)
+        ms = timeit(lambda: bp_hip.sense_mix(qk, c, out=out, lse=lse), a.iters)
+        res.append(dict(kernel='sense_mix', ms=ms, tflops=2 * pairs * d * (1 + K) * B / ms / 1e9,
+                        gbps=(4 + 2 * K + 2) * S * d * B / ms / 1e6))
+    if 'alpha' in which:
+        Ba = min(B, 8)
+        lse = bp_hip.sense_lse(qk[:Ba])
+        ms = timeit(lambda: bp_hip.sense_alpha(qk[:Ba], lse=lse), a.iters)
+        by = (4 * S * d + 2 * K * S * S) * Ba
+        res.append(dict(kernel='attn_probs(alpha)', batch=Ba, ms=ms, tflops=2 * pairs * d * Ba / ms / 1e9,
+                        gbps=by / ms / 1e6))
+    for r in res:
+        r.update(batch=r.get('batch', B), seq=S, dtype=a.dtype)
+        print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}), flush=True)
+
+
+if __name__ == '__main__':
+    main()
