@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libbackpack_hip.so')
+LIB_PATH = os.environ.get('BP_HIP_LIB') or os.path.join(_HERE, 'libbackpack_hip.so')  # env: A/B builds only
 ABI_VERSION = 1
 
 _lib = None

@@ -16,9 +16,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT_DIR = os.path.join(CSRC, 'build')
 LIB = os.path.join(HERE, 'bp_hip', 'libbackpack_hip.so')
-SOURCES = ['flash_fwd.hip', 'sense_mix.hip', 'attn_probs.hip', 'bp_api.hip']
-HEADERS = ['bp_common.h', 'bp_kernels.h', os.path.join('..', '..', 'include', 'bp_hip.h')]
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc',
+SOURCES = ['flash_fwd.hip', 'flash_fwd_dma.hip', 'sense_mix.hip', 'sense_mix_dma.hip', 'attn_probs.hip',
+           'bp_api.hip']
+HEADERS = ['bp_common.h', 'bp_dma.h', 'bp_kernels.h', os.path.join('..', '..', 'include', 'bp_hip.h')]
+# -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has one unified file); without it
+# hipcc parks them in AGPRs and copies 64+ registers per tile around the softmax (measured +4..10 %).
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-mllvm', '-amdgpu-mfma-vgpr-form=1',
          '-Wall', '-Wno-unused-variable', '-Wno-unused-but-set-variable']
 
 
@@ -38,19 +41,22 @@ def _stamp():
     return h.hexdigest()
 
 
-def build(force=False, verbose=False):
-    os.makedirs(OUT_DIR, exist_ok=True)
-    stamp_file = os.path.join(OUT_DIR, 'stamp.txt')
-    stamp = _stamp()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp_file):
+def build(force=False, verbose=False, extra_flags=(), lib=LIB, tag=''):
+    """`extra_flags` / `lib` / `tag` build an experimental variant next to the default library
+    (A/B measurements: BP_HIP_LIB=<path> selects it at run time)."""
+    out_dir = OUT_DIR + tag
+    os.makedirs(out_dir, exist_ok=True)
+    stamp_file = os.path.join(out_dir, 'stamp.txt')
+    stamp = _stamp() + ' '.join(extra_flags)
+    if not force and os.path.exists(lib) and os.path.exists(stamp_file):
         if open(stamp_file).read().strip() == stamp:
-            return LIB
+            return lib
     hipcc = _hipcc()
     t0 = time.time()
 
     def compile_one(src):
-        obj = os.path.join(OUT_DIR, src.replace('.hip', '.o'))
-        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+        obj = os.path.join(out_dir, src.replace('.hip', '.o'))
+        cmd = [hipcc] + FLAGS + list(extra_flags) + ['-c', os.path.join(CSRC, src), '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stderr[-8000:]))
@@ -60,16 +66,22 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs,
+    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs,
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('link failed:\n' + r.stderr[-8000:])
     with open(stamp_file, 'w') as f:
         f.write(stamp)
     if verbose:
-        print('built %s in %.1fs' % (LIB, time.time() - t0))
-    return LIB
+        print('built %s in %.1fs' % (lib, time.time() - t0))
+    return lib
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, verbose=True))
+    if '--variant' in sys.argv:   # python build_hip.py --variant NAME -- <extra hipcc flags>
+        name = sys.argv[sys.argv.index('--variant') + 1]
+        extra = sys.argv[sys.argv.index('--') + 1:]
+        print(build(force=True, verbose=True, extra_flags=extra, tag='_' + name,
+                    lib=LIB.replace('.so', '_' + name + '.so')))
+    else:
+        print(build(force='--force' in sys.argv, verbose=True))

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "../../include/bp_hip.h"
 #include "bp_common.h"
@@ -16,6 +18,21 @@ inline bool mult8(int64_t x) { return (x & 7) == 0; }
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 inline bool scale_ok(float s) { return isfinite(s) && s > 0.f; }
+
+// A/B switches for measurements only: BP_FLASH_IMPL=staged / BP_MIX_IMPL=staged force the
+// register-staged kernels even for shapes the LDS-DMA ring kernels accept.
+inline bool env_is(const char *name, const char *value) {
+    const char *e = getenv(name);
+    return e != nullptr && strcmp(e, value) == 0;
+}
+
+// 16-byte friendly shapes take the LDS-DMA ring kernel; anything else (odd head dims, unaligned
+// views) the register-staged kernel with its element-wise loader.
+inline hipError_t dispatch_flash(const bp::FlashParams &p, int dtype, bool vec, hipStream_t st) {
+    static const bool force_staged = env_is("BP_FLASH_IMPL", "staged");
+    if (vec && !force_staged) return bp::launch_flash_fwd_dma(p, dtype, st);
+    return bp::launch_flash_fwd(p, dtype, vec, st);
+}
 
 }  // namespace
 
@@ -74,7 +91,7 @@ int bp_flash_fwd(const void *q, const void *k, const void *v, void *out, float *
     if (v != nullptr)
         vec = vec && aligned16(v) && aligned16(out) && mult8(v_row_stride) && mult8(v_head_stride) &&
               mult8(o_row_stride) && mult8(o_head_stride);
-    hipError_t e = bp::launch_flash_fwd(p, dtype, vec, static_cast<hipStream_t>(stream));
+    hipError_t e = dispatch_flash(p, dtype, vec, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
 }
 
@@ -128,7 +145,7 @@ static int sense_lse(const void *qk, float *lse_ws, int batch, int seqlen, int n
     p.scale_log2e = softmax_scale * bp::kLog2e;
     const bool vec = (d_k % 8 == 0) && aligned16(qp) && aligned16(kp) && mult8(qk_bs) && mult8(qk_rs) &&
                      mult8(qk_ss);
-    hipError_t e = bp::launch_flash_fwd(p, dtype, vec, stream);
+    hipError_t e = dispatch_flash(p, dtype, vec, stream);
     return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
 }
 
@@ -206,7 +223,10 @@ int bp_sense_mix(const void *qk, const void *content, void *out, float *lse_ws, 
     const bool vec_c = (d_out % 8 == 0) && aligned16(content) && aligned16(out) && mult8(c_batch_stride) &&
                        mult8(c_row_stride) && mult8(c_sense_stride) && mult8(o_batch_stride) &&
                        mult8(o_row_stride);
-    hipError_t e = bp::launch_sense_mix(p, dtype, vec_qk, vec_c, st);
+    static const bool force_staged = env_is("BP_MIX_IMPL", "staged");
+    hipError_t e;
+    if (vec_qk && vec_c && !force_staged) e = bp::launch_sense_mix_dma(p, dtype, st);
+    else e = bp::launch_sense_mix(p, dtype, vec_qk, vec_c, st);
     return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
 }
 

@@ -1,0 +1,44 @@
+// LDS-DMA ring helpers shared by the fast-path kernels (flash_fwd_dma.hip, sense_mix_dma.hip).
+//
+// Tiles reach LDS with `global_load_lds_dwordx4` (64 lanes x 16 B per instruction, LDS destination
+// = wave-uniform base + lane*16, per-lane global source), completion is tracked by hand:
+//   * every wave issues the same number of DMA instructions per tile, so
+//     `s_waitcnt vmcnt(that number)` means "my share of the OLDEST tile in flight has landed";
+//   * one raw `s_barrier` per tile then makes everybody's share visible and, at the same time,
+//     retires the ring slot that was read during the previous step (it is refilled right after).
+// Because the DMA writes LDS linearly, the XOR swizzles that make the MFMA operand reads
+// bank-conflict free are applied to the per-lane SOURCE address.
+#pragma once
+#include "bp_common.h"
+
+namespace bp {
+
+typedef __attribute__((address_space(3))) void lmem_v;
+
+// One LDS-DMA instruction.  Inline asm ON PURPOSE: hipcc treats the builtin form
+// (__builtin_amdgcn_global_load_lds) as a pending LDS write and drains the whole DMA queue with
+// `s_waitcnt vmcnt(0)` in front of every ds_read_b64_tr_b16, which serialises the ring.  M0 carries
+// the LDS base; it is saved and restored inside the statement because the compiler owns M0.
+BP_DEV void dma16(const uint16_t *g, uint32_t lds_addr) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(g), "s"(lds_addr)
+        : "memory");
+}
+
+BP_DEV uint32_t lds_base_addr(char *smem) { return (uint32_t)(uintptr_t)(lmem_v *)smem; }
+
+template <int N> BP_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// K rows live in LDS with a power-of-two pitch (128 or 256 B) and XOR-swizzled 16-B slots:
+// ds_read_b128 by 32 lanes at 32 consecutive rows and one logical slot touches every bank once.
+// Only row bits 0..3 enter, so adding 32 rows keeps a lane's swizzle.
+template <int KROW> BP_DEV int k_swz(int row) { return KROW == 128 ? ((row >> 1) & 7) : (row & 15); }
+
+}  // namespace bp

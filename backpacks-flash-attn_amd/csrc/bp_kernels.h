@@ -51,7 +51,11 @@ struct MixParams {
 };
 
 hipError_t launch_flash_fwd(const FlashParams &p, int dtype, bool vec, hipStream_t stream);
+// LDS-DMA ring version; needs 16-byte friendly shapes (vec)
+hipError_t launch_flash_fwd_dma(const FlashParams &p, int dtype, hipStream_t stream);
 hipError_t launch_attn_probs(const ProbsParams &p, int dtype, bool vec, hipStream_t stream);
 hipError_t launch_sense_mix(const MixParams &p, int dtype, bool vec_qk, bool vec_c, hipStream_t stream);
+// LDS-DMA ring version; needs 16-byte friendly shapes (vec_qk && vec_c)
+hipError_t launch_sense_mix_dma(const MixParams &p, int dtype, hipStream_t stream);
 
 }  // namespace bp

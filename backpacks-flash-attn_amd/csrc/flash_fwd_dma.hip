@@ -1,0 +1,301 @@
+// Fused attention forward for gfx950, LDS-DMA ring version: the fast path for 16-byte friendly
+// shapes (head_dim % 8 == 0, aligned rows) -- every shape the reference kernel accepts
+// (csrc/flash_attn/fmha_api.cpp:245).  Same math and tile algebra as flash_fwd.hip; what changes:
+//   * K/V tiles (64 keys) go straight from global memory to a 3-slot LDS ring with
+//     global_load_lds_dwordx4: no VGPR staging, no ds_write pass, two tiles always in flight,
+//     counted s_waitcnt vmcnt + ONE raw s_barrier per tile (bp_dma.h);
+//   * K rows: power-of-two pitch + XOR slot swizzle, V rows: 64-B chunk swizzle, both applied on the
+//     DMA source address; every MFMA operand read is `lane base + immediate`;
+//   * a 32-key half of a diagonal tile that is entirely above a wave's rows is skipped.
+#include "bp_common.h"
+#include "bp_dma.h"
+#include "bp_kernels.h"
+
+namespace bp {
+
+template <int KD, int NV, bool HAS_V>
+struct FlashDmaCfg {
+    static constexpr int BM = 128, BN = 64, NT = 256, NWAVE = 4, NSTAGE = 3;
+    static constexpr int KROW = KD <= 4 ? 128 : 256;
+    static constexpr int KSLOTS = KROW / 16;
+    static constexpr int VROW = NV * 64;
+    static constexpr int VCH = NV * 4;
+    static constexpr int KTILE = BN * KROW;
+    static constexpr int VTILE = HAS_V ? BN * VROW : 0;
+    static constexpr int STAGE = KTILE + VTILE;
+    static constexpr int K_DMA = KTILE / 1024 / NWAVE;            // 2 or 4 per wave per tile
+    static constexpr int V_DMA = HAS_V ? VTILE / 1024 / NWAVE : 0;  // 1..4
+    static constexpr int DMA_PER_STAGE = K_DMA + V_DMA;
+    static constexpr int K_ROWS_PER_DMA = 1024 / KROW;
+};
+
+template <class ET, int KD, int NV, bool HAS_V>
+__global__ __launch_bounds__(256) void flash_fwd_dma_kernel(const FlashParams p) {
+    using C = FlashDmaCfg<KD, NV, HAS_V>;
+    using E = Elem<ET>;
+    __shared__ __attribute__((aligned(16))) char smem[C::NSTAGE * C::STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int hh = lane >> 5;
+
+    int bh, slot;
+    if (!xcd_map(blockIdx.x, p.b * p.h, p.n_qtiles, bh, slot)) return;
+    const int qt = p.n_qtiles - 1 - slot;
+    const int batch = bh / p.h;
+    const int head = bh - batch * p.h;
+
+    int seq_q, seq_k;
+    int64_t q_off, k_off, v_off, o_off;
+    if (p.cu_q != nullptr) {
+        const int a = p.cu_q[batch], b = p.cu_q[batch + 1];
+        const int c = p.cu_k[batch], d = p.cu_k[batch + 1];
+        seq_q = b - a; seq_k = d - c;
+        q_off = a * p.q_rs; o_off = a * p.o_rs; k_off = c * p.k_rs; v_off = c * p.v_rs;
+    } else {
+        seq_q = p.max_sq; seq_k = p.max_sk;
+        q_off = batch * p.q_bs; o_off = batch * p.o_bs; k_off = batch * p.k_bs; v_off = batch * p.v_bs;
+    }
+    if (qt * C::BM >= seq_q) return;
+
+    const uint16_t *qg = reinterpret_cast<const uint16_t *>(p.q) + q_off + (int64_t)head * p.q_hs;
+    const uint16_t *kg = reinterpret_cast<const uint16_t *>(p.k) + k_off + (int64_t)head * p.k_hs;
+    const uint16_t *vg = HAS_V ? reinterpret_cast<const uint16_t *>(p.v) + v_off + (int64_t)head * p.v_hs : nullptr;
+
+    int k_end = seq_k;
+    if (p.causal) k_end = min(seq_k, qt * C::BM + C::BM);
+    const int nkb = (k_end + C::BN - 1) / C::BN;
+
+    const int q0 = qt * C::BM + wave * 32;
+    const int my_q = q0 + l31;
+    const bool wave_has_rows = q0 < seq_q;
+    const float c2 = p.scale_log2e;
+
+    // K pad slots (head_dim not a multiple of 16, or pitch wider than the row) are never written by
+    // the DMA and meet zero Q columns in the MFMA: they must hold finite values -> zero them once.
+    if (p.d * 2 != C::KROW) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (int off = tid * 16; off < C::NSTAGE * C::STAGE; off += C::NT * 16) lds_write_16B(smem, off, z);
+        __syncthreads();
+    }
+
+    // ---- Q fragments (B operand of S^T = K Q^T) ----------------------------------------------------
+    u32x4 qf[KD];
+    {
+        const uint16_t *row = qg + (int64_t)min(my_q, seq_q - 1) * p.q_rs;
+#pragma unroll
+        for (int s = 0; s < KD; ++s) {
+            const int col = 16 * s + 8 * hh;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (col < p.d) v = ld_global_16B(row + col);
+            qf[s] = v;
+        }
+    }
+
+    // ---- per-lane DMA source descriptors -------------------------------------------------------------
+    int k_row[C::K_DMA], k_col[C::K_DMA];
+#pragma unroll
+    for (int j = 0; j < C::K_DMA; ++j) {
+        const int row = (wave * C::K_DMA + j) * C::K_ROWS_PER_DMA + lane / C::KSLOTS;
+        k_row[j] = row;
+        k_col[j] = ((lane % C::KSLOTS) ^ k_swz<C::KROW>(row)) * 8;
+    }
+    int v_row[HAS_V ? C::V_DMA : 1], v_col[HAS_V ? C::V_DMA : 1];
+    if (HAS_V) {
+#pragma unroll
+        for (int j = 0; j < C::V_DMA; ++j) {
+            const int c = (wave * C::V_DMA + j) * 64 + lane;   // linear 16-B chunk of the tile
+            const int row = c / C::VCH, stored = c - row * C::VCH;
+            int c64 = stored >> 2;
+            if (NV == 2) c64 ^= (row >> 1) & 1;
+            if (NV == 4) c64 ^= row & 3;
+            v_row[j] = row;
+            v_col[j] = ((c64 << 2) | (stored & 3)) * 8;
+        }
+    }
+    const uint32_t lds0 = lds_base_addr(smem);
+    auto issue = [&](int kb) {
+        const uint32_t stage = lds0 + (kb % C::NSTAGE) * C::STAGE;
+#pragma unroll
+        for (int j = 0; j < C::K_DMA; ++j) {
+            const int key = min(kb * C::BN + k_row[j], seq_k - 1);   // clamped rows are masked later
+            if (k_col[j] < p.d) dma16(kg + (int64_t)key * p.k_rs + k_col[j], stage + (wave * C::K_DMA + j) * 1024);
+        }
+        if (HAS_V) {
+#pragma unroll
+            for (int j = 0; j < C::V_DMA; ++j) {
+                const int key = min(kb * C::BN + v_row[j], seq_k - 1);
+                if (v_col[j] < p.d)
+                    dma16(vg + (int64_t)key * p.v_rs + v_col[j], stage + C::KTILE + (wave * C::V_DMA + j) * 1024);
+            }
+        }
+    };
+
+    f32x16 acc[HAS_V ? NV : 1];
+#pragma unroll
+    for (int n = 0; n < (HAS_V ? NV : 1); ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    float m_run = -INFINITY;
+    float l_run = 0.f;
+
+    int k_read_off[KD];
+#pragma unroll
+    for (int s = 0; s < KD; ++s) k_read_off[s] = l31 * C::KROW + (((2 * s + hh) ^ k_swz<C::KROW>(l31)) * 16);
+    int v_read_off[HAS_V ? NV : 1];
+    if (HAS_V) {
+        const int v_row_lane = 4 * hh + ((lane & 15) >> 2);
+        const int v_ch_lane = ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1);
+#pragma unroll
+        for (int n = 0; n < NV; ++n) v_read_off[n] = v_lds_off<NV>(v_row_lane, n * 4 + v_ch_lane) + (lane & 1) * 8;
+    }
+
+    auto block = [&](int kb, const char *kbuf, const char *vbuf, auto MASKED) {
+        constexpr bool kMasked = decltype(MASKED)::value;
+        // second 32-key half entirely above my rows?  (only possible on a masked tile)
+        const bool skip_hi = kMasked && p.causal && (kb * C::BN + 32 > q0 + 31);
+        f32x16 st[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (kk == 1 && skip_hi) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[kk][r] = -INFINITY;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[kk][r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < KD; ++s) {
+                    const u32x4 a = lds_read_16B(kbuf, k_read_off[s] + kk * 32 * C::KROW);
+                    st[kk] = E::mfma(a, qf[s], st[kk]);
+                }
+                if (kMasked) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kb * C::BN + kk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        const bool dead = key >= seq_k || (p.causal && key > my_q);
+                        if (dead) st[kk][r] = -INFINITY;
+                    }
+                }
+            }
+        }
+        float mx = st[0][0];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kk][r]);
+        mx = fmaxf(mx, xhalf(mx));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float mc = m_use * c2;
+        const float alpha = fast_exp2(m_run * c2 - mc);
+        m_run = m_new;
+        float rs = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = fast_exp2(fmaf(st[kk][r], c2, -mc));
+                st[kk][r] = e;
+                rs += e;
+            }
+        l_run = l_run * alpha + rs;
+        if (HAS_V) {
+#pragma unroll
+            for (int n = 0; n < NV; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[n][r] *= alpha;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                if (kk == 1 && skip_hi) continue;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    u32x4 pf;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        pf[i] = E::pack2(st[kk][ks * 8 + 2 * i], st[kk][ks * 8 + 2 * i + 1]);
+                    const int rows = (kk * 32 + ks * 16) * C::VROW;
+#pragma unroll
+                    for (int n = 0; n < NV; ++n) {
+                        const u32x2 lo = lds_read_tr16_8B(vbuf, v_read_off[n] + rows);
+                        const u32x2 hi = lds_read_tr16_8B(vbuf, v_read_off[n] + rows + 8 * C::VROW);
+                        const u32x4 a = {lo[0], lo[1], hi[0], hi[1]};
+                        acc[n] = E::mfma(a, pf, acc[n]);
+                    }
+                }
+            }
+        }
+    };
+
+    if (nkb > 0) issue(0);
+    if (nkb > 1) issue(1);
+    for (int kb = 0; kb < nkb; ++kb) {
+        if (kb + 1 < nkb) wait_vmcnt<C::DMA_PER_STAGE>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kb + 2 < nkb) issue(kb + 2);
+        const bool active = wave_has_rows && !(p.causal && kb * C::BN > q0 + 31);
+        if (active) {
+            const char *kbuf = smem + (kb % C::NSTAGE) * C::STAGE;
+            const char *vbuf = kbuf + C::KTILE;
+            const bool need_mask = (kb * C::BN + C::BN > seq_k) || (p.causal && kb * C::BN + C::BN - 1 > q0);
+            if (need_mask) block(kb, kbuf, vbuf, std::true_type{});
+            else block(kb, kbuf, vbuf, std::false_type{});
+        }
+    }
+
+    if (!wave_has_rows) return;
+    const float l_tot = l_run + xhalf(l_run);
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    if (my_q < seq_q) {
+        if (hh == 0 && p.lse != nullptr) {
+            const float lse = l_tot > 0.f ? (m_run * c2 + fast_log2(l_tot)) * kLn2 : -INFINITY;
+            p.lse[((int64_t)batch * p.h + head) * p.lse_stride + my_q] = lse;
+        }
+        if (HAS_V) {
+            uint16_t *og = reinterpret_cast<uint16_t *>(p.o) + o_off + (int64_t)my_q * p.o_rs + (int64_t)head * p.o_hs;
+#pragma unroll
+            for (int n = 0; n < NV; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = n * 32 + 8 * g + 4 * hh;
+                    if (d0 < p.d) {
+                        u32x2 w = {E::pack2(acc[n][4 * g + 0] * inv, acc[n][4 * g + 1] * inv),
+                                   E::pack2(acc[n][4 * g + 2] * inv, acc[n][4 * g + 3] * inv)};
+                        *reinterpret_cast<u32x2 *>(og + d0) = w;
+                    }
+                }
+        }
+    }
+}
+
+template <class ET, int KD, int NV, bool HAS_V>
+static hipError_t launch_one(const FlashParams &p, hipStream_t stream) {
+    const int grid = xcd_grid(p.b * p.h, p.n_qtiles);
+    hipLaunchKernelGGL((flash_fwd_dma_kernel<ET, KD, NV, HAS_V>), dim3(grid), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+template <class ET, bool HAS_V>
+static hipError_t launch_dim(const FlashParams &p, hipStream_t stream) {
+    switch ((p.d + 15) / 16) {
+        case 1: return launch_one<ET, 1, 1, HAS_V>(p, stream);
+        case 2: return launch_one<ET, 2, 1, HAS_V>(p, stream);
+        case 3: return launch_one<ET, 3, 2, HAS_V>(p, stream);
+        case 4: return launch_one<ET, 4, 2, HAS_V>(p, stream);
+        case 5: return launch_one<ET, 5, 3, HAS_V>(p, stream);
+        case 6: return launch_one<ET, 6, 3, HAS_V>(p, stream);
+        case 7: return launch_one<ET, 7, 4, HAS_V>(p, stream);
+        default: return launch_one<ET, 8, 4, HAS_V>(p, stream);
+    }
+}
+
+// Requires head_dim % 8 == 0, 16-byte aligned bases, strides multiples of 8, seq_k >= 1 per sequence
+// handled inside (nkb == 0 issues nothing).
+hipError_t launch_flash_fwd_dma(const FlashParams &p, int dtype, hipStream_t stream) {
+    const bool has_v = p.v != nullptr;
+    if (dtype == 1) return has_v ? launch_dim<BF16, true>(p, stream) : launch_dim<BF16, false>(p, stream);
+    return has_v ? launch_dim<F16, true>(p, stream) : launch_dim<F16, false>(p, stream);
+}
+
+}  // namespace bp

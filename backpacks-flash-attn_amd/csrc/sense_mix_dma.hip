@@ -1,0 +1,264 @@
+// Fused Backpack sense combination, LDS-DMA ring version (the fast path for 16-byte-aligned shapes).
+//
+//     out[b,t,:] = sum_l sum_{s<=t} exp(scale * q_l[t].k_l[s] - lse[b,l,t]) * C[b,s,l,:]
+//
+// Same contraction and tile algebra as sense_mix.hip (see there and bp_common.h); what changes is how
+// the K_l / C_l tiles reach LDS.  The register-staged kernel prefetches ONE 32-key tile ahead and is
+// latency-bound (rocprof r01_a: 61 % of wave cycles in s_waitcnt, L2 hit rate 15 %: four query
+// tiles sweep the same C at different speeds, so most tiles come from HBM / Infinity Cache).  Here
+//   * tiles are 64 keys (40 KB: 32 KB of C + 8 KB of K) in a 3-slot LDS ring (120 KB, one workgroup
+//     per CU), filled by `global_load_lds_dwordx4` (no VGPR round trip, no ds_write pass);
+//   * two tiles are always in flight (>= 2 us of HBM latency covered by >= 76 MFMAs per SIMD);
+//   * waits are COUNTED: each wave issues exactly DMA_PER_STAGE DMA instructions per tile, so
+//     `s_waitcnt vmcnt(DMA_PER_STAGE)` = "my share of the oldest tile has landed", then ONE raw
+//     `s_barrier` per tile makes every wave's share visible and retires the slot read last step;
+//   * the DMA writes LDS linearly (wave base + lane*16), so the XOR swizzles that make ds_read_b128
+//     (K) and ds_read_b64_tr_b16 (C) conflict-free are applied to the per-lane SOURCE address.
+// Rows past the sequence are fetched from a clamped (valid) row: their probabilities are exactly 0
+// by the causal mask and 0 * finite = 0; LDS is zeroed once so never-written pad slots are 0.
+#include "bp_common.h"
+#include "bp_dma.h"
+#include "bp_kernels.h"
+
+namespace bp {
+
+template <int KD>
+struct MixDmaCfg {
+    static constexpr int BM = 256, BK = 64, NB = 8, BNC = 256, NT = 512, NWAVE = 8, NSTAGE = 3;
+    static constexpr int KROW = KD <= 4 ? 128 : 256;   // bytes per K row (power of two, XOR-swizzled)
+    static constexpr int KSLOTS = KROW / 16;
+    static constexpr int CROW = 512;
+    static constexpr int KTILE = BK * KROW;
+    static constexpr int CTILE = BK * CROW;
+    static constexpr int STAGE = KTILE + CTILE;
+    static constexpr int K_DMA = KTILE / 1024 / NWAVE;   // DMA instructions per wave per tile (1 or 2)
+    static constexpr int C_DMA = CTILE / 1024 / NWAVE;   // 4
+    static constexpr int DMA_PER_STAGE = K_DMA + C_DMA;
+    static constexpr int K_ROWS_PER_DMA = 1024 / KROW;   // 8 or 4
+};
+
+template <class ET, int KD, bool FULL>
+__global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
+    using C = MixDmaCfg<KD>;
+    using E = Elem<ET>;
+    __shared__ __attribute__((aligned(16))) char smem[C::NSTAGE * C::STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int hh = lane >> 5;
+
+    int grp, slot;
+    if (!xcd_map(blockIdx.x, p.b * p.n_chunks, p.n_qtiles, grp, slot)) return;
+    const int qt = p.n_qtiles - 1 - slot;
+    const int batch = grp / p.n_chunks;
+    const int chunk = grp - batch * p.n_chunks;
+    const int col_base = chunk * C::BNC;
+    const int S = p.s;
+
+    const uint16_t *qg = reinterpret_cast<const uint16_t *>(p.q) + batch * p.qk_bs;
+    const uint16_t *kg = reinterpret_cast<const uint16_t *>(p.k) + batch * p.qk_bs;
+    const uint16_t *cg = reinterpret_cast<const uint16_t *>(p.c) + batch * p.c_bs;
+
+    const int k_end = min(S, qt * C::BM + C::BM);
+    const int nkb = (k_end + C::BK - 1) / C::BK;
+    const int nsteps = p.nsenses * nkb;
+
+    const int q0 = qt * C::BM + wave * 32;
+    const int my_q = q0 + l31;
+    const int my_q_clamped = min(my_q, S - 1);
+    const bool wave_has_rows = q0 < S;
+    const int my_diag_sub = q0 >> 5;   // index of the 32-key sub-block that holds my diagonal
+    const float c2 = p.scale_log2e;
+    const int nb_live = FULL ? C::NB : min(C::NB, (p.dout - col_base + 31) / 32);
+
+    // ---- zero the ring once: pad slots that no DMA ever writes must read as 0 -----------------------
+    {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (int off = tid * 16; off < C::NSTAGE * C::STAGE; off += C::NT * 16) lds_write_16B(smem, off, z);
+    }
+    __syncthreads();
+
+    // ---- per-lane DMA source descriptors (tile-invariant parts) ------------------------------------
+    // K piece j of this wave: rows (wave*K_DMA + j)*RPD + lane/KSLOTS, stored slot lane%KSLOTS
+    int k_row[C::K_DMA], k_col[C::K_DMA];
+    bool k_on[C::K_DMA];
+#pragma unroll
+    for (int j = 0; j < C::K_DMA; ++j) {
+        const int row = (wave * C::K_DMA + j) * C::K_ROWS_PER_DMA + lane / C::KSLOTS;
+        const int logical = (lane % C::KSLOTS) ^ k_swz<C::KROW>(row);
+        k_row[j] = row;
+        k_col[j] = logical * 8;
+        k_on[j] = logical * 8 < p.dk;
+    }
+    // C piece j of this wave: rows (wave*C_DMA + j)*2 + lane/32, stored chunk lane%32
+    int c_row[C::C_DMA], c_col[C::C_DMA];
+    bool c_on[C::C_DMA];
+#pragma unroll
+    for (int j = 0; j < C::C_DMA; ++j) {
+        const int row = (wave * C::C_DMA + j) * 2 + (lane >> 5);
+        const int stored = lane & 31;
+        const int logical = (((stored >> 2) ^ (row & 3)) << 2) | (stored & 3);
+        c_row[j] = row;
+        c_col[j] = col_base + logical * 8;
+        c_on[j] = c_col[j] < p.dout;
+    }
+
+    const uint32_t lds0 = lds_base_addr(smem);
+    auto issue = [&](int step) {
+        const int l = step / nkb;
+        const int kb = step - l * nkb;
+        const uint32_t stage_off = lds0 + (step % C::NSTAGE) * C::STAGE;
+        const uint16_t *kl = kg + (int64_t)l * p.qk_ss;
+        const uint16_t *cl = cg + (int64_t)l * p.c_ss;
+#pragma unroll
+        for (int j = 0; j < C::K_DMA; ++j) {
+            const int key = min(kb * C::BK + k_row[j], S - 1);
+            const uint16_t *src = kl + (int64_t)key * p.qk_rs + k_col[j];
+            if (k_on[j]) dma16(src, stage_off + (wave * C::K_DMA + j) * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < C::C_DMA; ++j) {
+            const int key = min(kb * C::BK + c_row[j], S - 1);
+            const uint16_t *src = cl + (int64_t)key * p.c_rs + c_col[j];
+            if (c_on[j]) dma16(src, stage_off + C::KTILE + (wave * C::C_DMA + j) * 1024);
+        }
+    };
+
+    f32x16 acc[C::NB];
+#pragma unroll
+    for (int n = 0; n < C::NB; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+
+    // lane-constant LDS read offsets
+    int k_read_off[KD];   // K fragment (A operand of S^T): row l31 (+32*kk), logical slot 2*s + hh
+#pragma unroll
+    for (int s = 0; s < KD; ++s)
+        k_read_off[s] = l31 * C::KROW + (((2 * s + hh) ^ k_swz<C::KROW>(l31)) * 16);
+    // (k_swz only looks at row bits 0..3, so +32 rows keeps the same swizzle)
+    const int c_row_lane = 4 * hh + ((lane & 15) >> 2);
+    const int c_ch_lane = ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1);
+    int c_read_off[C::NB];   // C^T fragment: (row c_row_lane, 16-col group of block n), +8 rows keeps swizzle
+#pragma unroll
+    for (int n = 0; n < C::NB; ++n) c_read_off[n] = v_lds_off<C::NB>(c_row_lane, n * 4 + c_ch_lane) + (lane & 1) * 8;
+
+    u32x4 qf[KD];
+    float lse2 = 0.f;
+
+    // ---- prologue: two tiles in flight ----------------------------------------------------------------
+    issue(0);
+    if (nsteps > 1) issue(1);
+
+    for (int step = 0; step < nsteps; ++step) {
+        const int l = step / nkb;
+        const int kb = step - l * nkb;
+        // my share of tile `step` has landed (the tile after it may still be in flight) ...
+        if (step + 1 < nsteps) wait_vmcnt<C::DMA_PER_STAGE>(); else wait_vmcnt<0>();
+        // ... and so has everybody else's; all waves are also done reading tile step-1
+        __builtin_amdgcn_s_barrier();
+        if (kb == 0 && wave_has_rows) {
+            // new sense: my query's fragments (B operand of S^T = K Q^T) and its log-sum-exp
+            const uint16_t *row = qg + (int64_t)my_q_clamped * p.qk_rs + (int64_t)l * p.qk_ss;
+#pragma unroll
+            for (int s = 0; s < KD; ++s) {
+                const int col = 16 * s + 8 * hh;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (col < p.dk) v = ld_global_16B(row + col);
+                qf[s] = v;
+            }
+            lse2 = p.lse[((int64_t)batch * p.nsenses + l) * p.lse_stride + my_q_clamped] * kLog2e;
+        }
+        if (step + 2 < nsteps) issue(step + 2);   // refill the slot that was read during step-1
+
+        if (wave_has_rows) {
+            const char *kbuf = smem + (step % C::NSTAGE) * C::STAGE;
+            const char *cbuf = kbuf + C::KTILE;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int sub = kb * 2 + kk;
+                if (sub <= my_diag_sub) {
+                    f32x16 st;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+                    for (int s = 0; s < KD; ++s) {
+                        const u32x4 a = lds_read_16B(kbuf, k_read_off[s] + kk * 32 * C::KROW);
+                        st = E::mfma(a, qf[s], st);
+                    }
+                    const bool diag = (sub == my_diag_sub);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float e = fast_exp2(fmaf(st[r], c2, -lse2));
+                        if (diag) {
+                            const int key = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                            if (key > my_q) e = 0.f;
+                        }
+                        st[r] = e;
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        u32x4 pf;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) pf[i] = E::pack2(st[ks * 8 + 2 * i], st[ks * 8 + 2 * i + 1]);
+                        const int rows = (kk * 32 + ks * 16) * C::CROW;
+#pragma unroll
+                        for (int n = 0; n < C::NB; ++n) {
+                            if (FULL || n < nb_live) {
+                                const u32x2 lo = lds_read_tr16_8B(cbuf, c_read_off[n] + rows);
+                                const u32x2 hi = lds_read_tr16_8B(cbuf, c_read_off[n] + rows + 8 * C::CROW);
+                                const u32x4 a = {lo[0], lo[1], hi[0], hi[1]};
+                                acc[n] = E::mfma(a, pf, acc[n]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (!wave_has_rows || my_q >= S) return;
+    uint16_t *og = reinterpret_cast<uint16_t *>(p.o) + batch * p.o_bs + (int64_t)my_q * p.o_rs;
+#pragma unroll
+    for (int n = 0; n < C::NB; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = col_base + n * 32 + 8 * g + 4 * hh;
+            if (col < p.dout) {
+                u32x2 w = {E::pack2(acc[n][4 * g + 0], acc[n][4 * g + 1]),
+                           E::pack2(acc[n][4 * g + 2], acc[n][4 * g + 3])};
+                *reinterpret_cast<u32x2 *>(og + col) = w;
+            }
+        }
+}
+
+template <class ET, int KD>
+static hipError_t launch_kd(const MixParams &p, hipStream_t stream) {
+    const int grid = xcd_grid(p.b * p.n_chunks, p.n_qtiles);
+    dim3 g(grid), t(512);
+    if (p.dout % 256 == 0) hipLaunchKernelGGL((sense_mix_dma_kernel<ET, KD, true>), g, t, 0, stream, p);
+    else hipLaunchKernelGGL((sense_mix_dma_kernel<ET, KD, false>), g, t, 0, stream, p);
+    return hipGetLastError();
+}
+
+template <class ET>
+static hipError_t launch_et(const MixParams &p, hipStream_t stream) {
+    switch ((p.dk + 15) / 16) {
+        case 1: return launch_kd<ET, 1>(p, stream);
+        case 2: return launch_kd<ET, 2>(p, stream);
+        case 3: return launch_kd<ET, 3>(p, stream);
+        case 4: return launch_kd<ET, 4>(p, stream);
+        case 5: return launch_kd<ET, 5>(p, stream);
+        case 6: return launch_kd<ET, 6>(p, stream);
+        case 7: return launch_kd<ET, 7>(p, stream);
+        default: return launch_kd<ET, 8>(p, stream);
+    }
+}
+
+// Requires: d_k % 8 == 0, d_out % 8 == 0, all bases 16-byte aligned, all strides multiples of 8.
+hipError_t launch_sense_mix_dma(const MixParams &p, int dtype, hipStream_t stream) {
+    return dtype == 1 ? launch_et<BF16>(p, stream) : launch_et<F16>(p, stream);
+}
+
+}  // namespace bp
