@@ -217,6 +217,7 @@ int bp_sense_mix(const void *qk, const void *content, void *out, float *lse_ws, 
     p.b = batch; p.s = seqlen; p.nsenses = nsenses; p.dk = d_k; p.dout = d_out;
     p.n_qtiles = (seqlen + 255) / 256;
     p.n_chunks = (d_out + 255) / 256;
+    p.order = env_is("BP_MIX_ORDER", "grouped") ? 0 : 1;
     p.scale_log2e = softmax_scale * bp::kLog2e;
     const bool vec_qk = (d_k % 8 == 0) && aligned16(p.q) && aligned16(p.k) && mult8(qk_batch_stride) &&
                         mult8(qk_row_stride) && mult8(qk_sense_stride);

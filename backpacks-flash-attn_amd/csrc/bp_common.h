@@ -109,8 +109,37 @@ template <int NV> BP_DEV int v_lds_off(int row, int ch) {
 BP_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 BP_DEV float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 
-// exchange with the other half-wave (lane ^ 32)
+// exchange with the other half-wave (lane ^ 32) through the LDS crossbar (ds_bpermute)
 BP_DEV float xhalf(float x) { return __shfl_xor(x, 32); }
+
+// max / sum of x over the two half-waves (lanes l and l^32), result in both lanes, with ONE
+// v_permlane32_swap instead of an LDS round trip: the swap exchanges lanes 32..63 of its first
+// operand with lanes 0..31 of its second, so {r0, r1} hold {own, other} in one order or the other.
+#ifdef BP_DEBUG_NO_PERMLANE
+BP_DEV float xhalf_max(float x) { return fmaxf(x, __shfl_xor(x, 32)); }
+BP_DEV float xhalf_sum(float x) { return x + __shfl_xor(x, 32); }
+#else
+// Written as inline asm: with the builtin (__builtin_amdgcn_permlane32_swap) hipcc / ROCm 7.2 drops
+// the second result at -O3 (extractvalue 1 is replaced by extractvalue 0 in the IR: max(r0,r1) -> r0,
+// r0+r1 -> 2*r0; seen in the ISA, caught by the parity tests).  `s_nop 1` covers the
+// "VALU write -> v_permlane read" hazard (2 wait states) that the compiler cannot see inside asm.
+BP_DEV void xhalf_pair(float x, float &a, float &b) {
+    float u = x, w = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(u), "+v"(w));
+    a = u;
+    b = w;
+}
+BP_DEV float xhalf_max(float x) {
+    float a, b;
+    xhalf_pair(x, a, b);
+    return fmaxf(a, b);
+}
+BP_DEV float xhalf_sum(float x) {
+    float a, b;
+    xhalf_pair(x, a, b);
+    return a + b;
+}
+#endif
 
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;

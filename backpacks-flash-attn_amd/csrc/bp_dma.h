@@ -32,6 +32,25 @@ BP_DEV void dma16(const uint16_t *g, uint32_t lds_addr) {
         : "memory");
 }
 
+// Same, "saddr" form: wave-uniform 64-bit base in SGPRs + per-lane 32-bit BYTE offset.  The per-tile
+// address update then happens on the scalar unit (base += tile stride) and costs no VALU.
+BP_DEV void dma16_s(const uint16_t *uniform_base, uint32_t lane_byte_off, uint32_t lds_addr) {
+#ifdef BP_DEBUG_NO_SADDR
+    dma16(reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(uniform_base) + lane_byte_off), lds_addr);
+    return;
+#endif
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane_byte_off), "s"(uniform_base), "s"(lds_addr)
+        : "memory");
+}
+
 BP_DEV uint32_t lds_base_addr(char *smem) { return (uint32_t)(uintptr_t)(lmem_v *)smem; }
 
 template <int N> BP_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }

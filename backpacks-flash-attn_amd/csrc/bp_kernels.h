@@ -47,6 +47,7 @@ struct MixParams {
     int b, s, nsenses, dk, dout;
     int n_qtiles;             // ceil(s / 256)
     int n_chunks;             // ceil(dout / 256)
+    int order;                // work order: 0 = all query tiles of a group adjacent, 1 = heaviest tiles of ALL groups first
     float scale_log2e;
 };
 

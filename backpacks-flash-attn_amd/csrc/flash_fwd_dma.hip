@@ -94,15 +94,18 @@ __global__ __launch_bounds__(256) void flash_fwd_dma_kernel(const FlashParams p)
         }
     }
 
-    // ---- per-lane DMA source descriptors -------------------------------------------------------------
+    // ---- per-lane DMA source descriptors: tile row / column of the 16-B chunk this lane moves ----------
     int k_row[C::K_DMA], k_col[C::K_DMA];
+    uint32_t k_voff[C::K_DMA];
 #pragma unroll
     for (int j = 0; j < C::K_DMA; ++j) {
         const int row = (wave * C::K_DMA + j) * C::K_ROWS_PER_DMA + lane / C::KSLOTS;
         k_row[j] = row;
         k_col[j] = ((lane % C::KSLOTS) ^ k_swz<C::KROW>(row)) * 8;
+        k_voff[j] = (uint32_t)(row * p.k_rs + k_col[j]) * 2u;
     }
     int v_row[HAS_V ? C::V_DMA : 1], v_col[HAS_V ? C::V_DMA : 1];
+    uint32_t v_voff[HAS_V ? C::V_DMA : 1];
     if (HAS_V) {
 #pragma unroll
         for (int j = 0; j < C::V_DMA; ++j) {
@@ -113,22 +116,29 @@ __global__ __launch_bounds__(256) void flash_fwd_dma_kernel(const FlashParams p)
             if (NV == 4) c64 ^= row & 3;
             v_row[j] = row;
             v_col[j] = ((c64 << 2) | (stored & 3)) * 8;
+            v_voff[j] = (uint32_t)(row * p.v_rs + v_col[j]) * 2u;
         }
     }
     const uint32_t lds0 = lds_base_addr(smem);
+    // Full tiles: scalar base (+= 64 rows per tile) + constant per-lane byte offset -> no VALU at all.
+    // The last, partial tile clamps its rows to the final valid one (those keys are masked later).
     auto issue = [&](int kb) {
         const uint32_t stage = lds0 + (kb % C::NSTAGE) * C::STAGE;
+        const uint16_t *kt = kg + (int64_t)kb * C::BN * p.k_rs;
+        const uint16_t *vt = HAS_V ? vg + (int64_t)kb * C::BN * p.v_rs : nullptr;
+        const bool full = kb * C::BN + C::BN <= seq_k;
 #pragma unroll
         for (int j = 0; j < C::K_DMA; ++j) {
-            const int key = min(kb * C::BN + k_row[j], seq_k - 1);   // clamped rows are masked later
-            if (k_col[j] < p.d) dma16(kg + (int64_t)key * p.k_rs + k_col[j], stage + (wave * C::K_DMA + j) * 1024);
+            uint32_t off = k_voff[j];
+            if (!full) off = (uint32_t)(min(k_row[j], seq_k - 1 - kb * C::BN) * p.k_rs + k_col[j]) * 2u;
+            if (k_col[j] < p.d) dma16_s(kt, off, stage + (wave * C::K_DMA + j) * 1024);
         }
         if (HAS_V) {
 #pragma unroll
             for (int j = 0; j < C::V_DMA; ++j) {
-                const int key = min(kb * C::BN + v_row[j], seq_k - 1);
-                if (v_col[j] < p.d)
-                    dma16(vg + (int64_t)key * p.v_rs + v_col[j], stage + C::KTILE + (wave * C::V_DMA + j) * 1024);
+                uint32_t off = v_voff[j];
+                if (!full) off = (uint32_t)(min(v_row[j], seq_k - 1 - kb * C::BN) * p.v_rs + v_col[j]) * 2u;
+                if (v_col[j] < p.d) dma16_s(vt, off, stage + C::KTILE + (wave * C::V_DMA + j) * 1024);
             }
         }
     };
@@ -180,26 +190,39 @@ __global__ __launch_bounds__(256) void flash_fwd_dma_kernel(const FlashParams p)
                 }
             }
         }
-        float mx = st[0][0];
+        // row max: four independent chains (short dependency depth), then the other half-wave
+        // (plain fmaxf chains: hipcc fuses each pair into one v_max3_f32 and knows the MFMA->VALU
+        //  read hazard, which an inline-asm v_max3 on fresh MFMA results would bypass)
+        float mxa = st[0][0], mxb = st[0][8], mxc = st[1][0], mxd = st[1][8];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kk][r]);
-        mx = fmaxf(mx, xhalf(mx));
-        const float m_new = fmaxf(m_run, mx);
+        for (int r = 1; r < 8; ++r) {
+            mxa = fmaxf(mxa, st[0][r]);
+            mxb = fmaxf(mxb, st[0][8 + r]);
+            mxc = fmaxf(mxc, st[1][r]);
+            mxd = fmaxf(mxd, st[1][8 + r]);
+        }
+        const float mx = xhalf_max(fmaxf(fmaxf(fmaxf(mxa, mxb), fmaxf(mxc, mxd)), m_run));
+        const float m_new = mx;   // already includes m_run
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
         const float mc = m_use * c2;
         const float alpha = fast_exp2(m_run * c2 - mc);
         m_run = m_new;
-        float rs = 0.f;
+        // p = exp2(s*c2 - mc): packed fma on register pairs, packed row-sum accumulation
+        const f32x2 c2v = {c2, c2}, mcv = {-mc, -mc};
+        f32x2 rs2 = {0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = fast_exp2(fmaf(st[kk][r], c2, -mc));
-                st[kk][r] = e;
-                rs += e;
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 x = {st[kk][r], st[kk][r + 1]};
+                x = __builtin_elementwise_fma(x, c2v, mcv);
+                x[0] = fast_exp2(x[0]);
+                x[1] = fast_exp2(x[1]);
+                st[kk][r] = x[0];
+                st[kk][r + 1] = x[1];
+                rs2 += x;
             }
+        const float rs = rs2[0] + rs2[1];
         l_run = l_run * alpha + rs;
         if (HAS_V) {
 #pragma unroll
@@ -245,7 +268,7 @@ __global__ __launch_bounds__(256) void flash_fwd_dma_kernel(const FlashParams p)
     }
 
     if (!wave_has_rows) return;
-    const float l_tot = l_run + xhalf(l_run);
+    const float l_tot = xhalf_sum(l_run);
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
     if (my_q < seq_q) {
         if (hh == 0 && p.lse != nullptr) {

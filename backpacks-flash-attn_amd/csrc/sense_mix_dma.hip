@@ -50,7 +50,18 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
     const int hh = lane >> 5;
 
     int grp, slot;
-    if (!xcd_map(blockIdx.x, p.b * p.n_chunks, p.n_qtiles, grp, slot)) return;
+    if (p.order == 0) {
+        if (!xcd_map(blockIdx.x, p.b * p.n_chunks, p.n_qtiles, grp, slot)) return;
+    } else {
+        // heaviest query tiles of every group first (list scheduling with the longest jobs first),
+        // a group still always lands on the same XCD
+        const int ngroups = p.b * p.n_chunks;
+        const int per_xcd = (ngroups + 7) / 8;
+        const int s8 = blockIdx.x >> 3;
+        slot = s8 / per_xcd;
+        grp = (s8 - slot * per_xcd) * 8 + (blockIdx.x & 7);
+        if (grp >= ngroups) return;
+    }
     const int qt = p.n_qtiles - 1 - slot;
     const int batch = grp / p.n_chunks;
     const int chunk = grp - batch * p.n_chunks;
@@ -173,43 +184,55 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
         if (step + 2 < nsteps) issue(step + 2);   // refill the slot that was read during step-1
 
         if (wave_has_rows) {
-            const char *kbuf = smem + (step % C::NSTAGE) * C::STAGE;
-            const char *cbuf = kbuf + C::KTILE;
+            const int stage_off = (step % C::NSTAGE) * C::STAGE;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int sub = kb * 2 + kk;
                 if (sub <= my_diag_sub) {
+                    // one 32-key sub-block: S^T (KD MFMAs) -> P^T -> O^T += C^T P^T (2*NB MFMAs)
+                    const int koff = stage_off + kk * 32 * C::KROW;
+                    const int coff = stage_off + C::KTILE + kk * 32 * C::CROW;
                     f32x16 st;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
                     for (int s = 0; s < KD; ++s) {
-                        const u32x4 a = lds_read_16B(kbuf, k_read_off[s] + kk * 32 * C::KROW);
+                        const u32x4 a = lds_read_16B(smem, k_read_off[s] + koff);
                         st = E::mfma(a, qf[s], st);
                     }
-                    const bool diag = (sub == my_diag_sub);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float e = fast_exp2(fmaf(st[r], c2, -lse2));
-                        if (diag) {
-                            const int key = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                            if (key > my_q) e = 0.f;
-                        }
-                        st[r] = e;
+                    for (int r = 0; r < 16; ++r) st[r] = fast_exp2(fmaf(st[r], c2, -lse2));
+                    u32x4 pf[2];
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            pf[ks][i] = E::pack2(st[ks * 8 + 2 * i], st[ks * 8 + 2 * i + 1]);
+                    if (sub == my_diag_sub) {
+                        // Diagonal sub-block (its first key is q0): clear the 16-bit P entries whose key
+                        // lies above my query.  Done on the packed words with AND masks, in a small
+                        // wave-uniform branch, so the common path carries no mask arithmetic and the MFMA
+                        // code exists once.  (AND also kills an inf from an invisible, larger score.)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int r0 = ks * 8 + 2 * i;
+                                const int rel0 = (r0 & 3) + 8 * (r0 >> 2) + 4 * hh;   // rel of r0 + 1 is rel0 + 1
+                                const uint32_t keep = (rel0 <= l31 ? 0x0000ffffu : 0u) | (rel0 + 1 <= l31 ? 0xffff0000u : 0u);
+                                pf[ks][i] &= keep;
+                            }
                     }
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
-                        u32x4 pf;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) pf[i] = E::pack2(st[ks * 8 + 2 * i], st[ks * 8 + 2 * i + 1]);
-                        const int rows = (kk * 32 + ks * 16) * C::CROW;
+                        const int rows = coff + ks * 16 * C::CROW;
 #pragma unroll
                         for (int n = 0; n < C::NB; ++n) {
                             if (FULL || n < nb_live) {
-                                const u32x2 lo = lds_read_tr16_8B(cbuf, c_read_off[n] + rows);
-                                const u32x2 hi = lds_read_tr16_8B(cbuf, c_read_off[n] + rows + 8 * C::CROW);
+                                const u32x2 lo = lds_read_tr16_8B(smem, c_read_off[n] + rows);
+                                const u32x2 hi = lds_read_tr16_8B(smem, c_read_off[n] + rows + 8 * C::CROW);
                                 const u32x4 a = {lo[0], lo[1], hi[0], hi[1]};
-                                acc[n] = E::mfma(a, pf, acc[n]);
+                                acc[n] = E::mfma(a, pf[ks], acc[n]);
                             }
                         }
                     }
