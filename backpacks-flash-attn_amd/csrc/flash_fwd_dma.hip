@@ -11,11 +11,19 @@
 #include "bp_dma.h"
 #include "bp_kernels.h"
 
+// tuning knobs (compile-time; defaults are the measured best)
+#ifndef BP_FLASH_STAGES
+#define BP_FLASH_STAGES 2
+#endif
+#ifndef BP_FLASH_MINWAVES
+#define BP_FLASH_MINWAVES 1
+#endif
+
 namespace bp {
 
 template <int KD, int NV, bool HAS_V>
 struct FlashDmaCfg {
-    static constexpr int BM = 128, BN = 64, NT = 256, NWAVE = 4, NSTAGE = 3;
+    static constexpr int BM = 128, BN = 64, NT = 256, NWAVE = 4, NSTAGE = BP_FLASH_STAGES;
     static constexpr int KROW = KD <= 4 ? 128 : 256;
     static constexpr int KSLOTS = KROW / 16;
     static constexpr int VROW = NV * 64;
@@ -30,7 +38,7 @@ struct FlashDmaCfg {
 };
 
 template <class ET, int KD, int NV, bool HAS_V>
-__global__ __launch_bounds__(256) void flash_fwd_dma_kernel(const FlashParams p) {
+__global__ __launch_bounds__(256, BP_FLASH_MINWAVES) void flash_fwd_dma_kernel(const FlashParams p) {
     using C = FlashDmaCfg<KD, NV, HAS_V>;
     using E = Elem<ET>;
     __shared__ __attribute__((aligned(16))) char smem[C::NSTAGE * C::STAGE];
@@ -177,7 +185,12 @@ __global__ __launch_bounds__(256) void flash_fwd_dma_kernel(const FlashParams p)
                 for (int r = 0; r < 16; ++r) st[kk][r] = 0.f;
 #pragma unroll
                 for (int s = 0; s < KD; ++s) {
+#ifdef BP_ABL_NOLDS   // ablation: operand from registers instead of LDS (wrong results, timing only)
+                    u32x4 a = qf[(s + 1) % KD];
+                    asm volatile("" : "+v"(a));
+#else
                     const u32x4 a = lds_read_16B(kbuf, k_read_off[s] + kk * 32 * C::KROW);
+#endif
                     st[kk] = E::mfma(a, qf[s], st[kk]);
                 }
                 if (kMasked) {
@@ -216,15 +229,22 @@ __global__ __launch_bounds__(256) void flash_fwd_dma_kernel(const FlashParams p)
             for (int r = 0; r < 16; r += 2) {
                 f32x2 x = {st[kk][r], st[kk][r + 1]};
                 x = __builtin_elementwise_fma(x, c2v, mcv);
+#ifndef BP_ABL_NOEXP   // ablation builds only (timing experiments, results are wrong)
                 x[0] = fast_exp2(x[0]);
                 x[1] = fast_exp2(x[1]);
+#endif
                 st[kk][r] = x[0];
                 st[kk][r + 1] = x[1];
                 rs2 += x;
             }
         const float rs = rs2[0] + rs2[1];
         l_run = l_run * alpha + rs;
+#ifdef BP_ABL_NOPV
+        asm volatile("" ::"v"(st[0][0]), "v"(st[0][15]), "v"(st[1][0]), "v"(st[1][15]), "v"(alpha));
+        if (false) {
+#else
         if (HAS_V) {
+#endif
 #pragma unroll
             for (int n = 0; n < NV; ++n)
 #pragma unroll
@@ -241,22 +261,45 @@ __global__ __launch_bounds__(256) void flash_fwd_dma_kernel(const FlashParams p)
                     const int rows = (kk * 32 + ks * 16) * C::VROW;
 #pragma unroll
                     for (int n = 0; n < NV; ++n) {
+#ifdef BP_ABL_NOLDS
+                        u32x4 a = qf[n % KD];
+                        asm volatile("" : "+v"(a));
+#else
                         const u32x2 lo = lds_read_tr16_8B(vbuf, v_read_off[n] + rows);
                         const u32x2 hi = lds_read_tr16_8B(vbuf, v_read_off[n] + rows + 8 * C::VROW);
                         const u32x4 a = {lo[0], lo[1], hi[0], hi[1]};
+#endif
+#ifdef BP_FLASH_SETPRIO
+                        __builtin_amdgcn_s_setprio(1);
+#endif
                         acc[n] = E::mfma(a, pf, acc[n]);
+#ifdef BP_FLASH_SETPRIO
+                        __builtin_amdgcn_s_setprio(0);
+#endif
                     }
                 }
             }
         }
     };
 
-    if (nkb > 0) issue(0);
-    if (nkb > 1) issue(1);
+    // ring: NSTAGE-1 tiles are in flight before a tile is consumed
+#pragma unroll
+    for (int t = 0; t < C::NSTAGE - 1; ++t)
+        if (t < nkb) issue(t);
     for (int kb = 0; kb < nkb; ++kb) {
-        if (kb + 1 < nkb) wait_vmcnt<C::DMA_PER_STAGE>(); else wait_vmcnt<0>();
+        // tiles kb+1 .. kb+NSTAGE-2 may still be in flight; tile kb must have landed
+        const int later = min(nkb - 1 - kb, C::NSTAGE - 2);
+#ifndef BP_ABL_NOVMWAIT
+        if (later >= 2) wait_vmcnt<2 * C::DMA_PER_STAGE>();
+        else if (later == 1) wait_vmcnt<C::DMA_PER_STAGE>();
+        else wait_vmcnt<0>();
+#endif
+#ifndef BP_ABL_NOBARRIER
         __builtin_amdgcn_s_barrier();
-        if (kb + 2 < nkb) issue(kb + 2);
+#endif
+#ifndef BP_ABL_NODMA
+        if (kb + C::NSTAGE - 1 < nkb) issue(kb + C::NSTAGE - 1);
+#endif
         const bool active = wave_has_rows && !(p.causal && kb * C::BN > q0 + 31);
         if (active) {
             const char *kbuf = smem + (kb % C::NSTAGE) * C::STAGE;
