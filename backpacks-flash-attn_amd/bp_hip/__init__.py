@@ -28,6 +28,7 @@ SIGNATURES = {
     'bp_sense_lse': (_i32, [_ptr] * 2 + [_i32] * 4 + [_i64] * 4 + [_f32, _i32, _ptr]),
     'bp_sense_alpha': (_i32, [_ptr] * 3 + [_i32] * 5 + [_i64] * 4 + [_f32, _i32, _ptr]),
     'bp_sense_mix': (_i32, [_ptr] * 4 + [_i32] * 6 + [_i64] * 9 + [_f32, _i32, _ptr]),
+    'bp_add_layer_norm': (_i32, [_ptr] * 6 + [_i64, _i32, _f32] + [_i32] * 4 + [_ptr]),
 }
 
 
@@ -217,3 +218,41 @@ def sense_mix(qk, content, softmax_scale=None, out=None, lse=None):
                                   float(scale), _dtype_code(qk), _stream())
     _check(code, 'bp_sense_mix')
     return out
+
+
+def add_layer_norm(x0, x1, weight, bias, eps, residual_dtype=None, return_residual=True):
+    """Fused z = LayerNorm(x0 + x1) (fp32 math) and the updated residual stream x = x0 + x1.
+
+    x0 (..., cols) fp16/bf16 contiguous; x1 same shape (fp32 or x0's dtype) or None; weight/bias
+    (cols,) fp32 or x0's dtype.  Returns (z in x0's dtype, x in residual_dtype) -- or z alone.
+    residual_dtype defaults to x1's dtype (reference rule, csrc/layer_norm/ln_api.cpp:99-102).
+    Replaces dropout_add_layer_norm with dropout_p = 0 (flash_attn/ops/layer_norm.py:207-217)."""
+    _require_cuda(x0, x1, weight, bias)
+    code_dt = _dtype_code(x0)
+    cols = x0.shape[-1]
+    if weight.shape != (cols,) or bias.shape != (cols,) or weight.dtype != bias.dtype:
+        raise RuntimeError('bp_hip.add_layer_norm: weight/bias must be (cols,) of one dtype')
+    if weight.dtype not in (torch.float32, x0.dtype):
+        raise RuntimeError('bp_hip.add_layer_norm: weight dtype must be fp32 or the input dtype')
+    x0c = x0.contiguous()
+    x1c = None
+    if x1 is not None:
+        if x1.shape != x0.shape or x1.dtype not in (torch.float32, x0.dtype):
+            raise RuntimeError('bp_hip.add_layer_norm: residual must match x0 (fp32 or input dtype)')
+        x1c = x1.contiguous()
+    if residual_dtype is None:
+        residual_dtype = x1.dtype if x1 is not None else x0.dtype
+    if residual_dtype not in (torch.float32, x0.dtype):
+        raise RuntimeError('bp_hip.add_layer_norm: residual dtype must be fp32 or the input dtype')
+    z = torch.empty_like(x0c)
+    xo = torch.empty(x0c.shape, dtype=residual_dtype, device=x0.device) if return_residual else None
+    rows = x0c.numel() // cols
+    wc, bc = weight.contiguous(), bias.contiguous()
+    with torch.cuda.device(x0.device):
+        code = lib().bp_add_layer_norm(
+            x0c.data_ptr(), x1c.data_ptr() if x1c is not None else None, wc.data_ptr(), bc.data_ptr(),
+            z.data_ptr(), xo.data_ptr() if xo is not None else None, rows, cols, float(eps), code_dt,
+            int(x1c is not None and x1c.dtype == torch.float32), int(residual_dtype == torch.float32),
+            int(weight.dtype == torch.float32), _stream())
+    _check(code, 'bp_add_layer_norm')
+    return (z, xo) if return_residual else z

@@ -231,4 +231,24 @@ int bp_sense_mix(const void *qk, const void *content, void *out, float *lse_ws, 
     return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
 }
 
+int bp_add_layer_norm(const void *x0, const void *x1, const void *gamma, const void *beta, void *z,
+                      void *x_out, int64_t rows, int cols, float epsilon, int dtype, int x1_is_f32,
+                      int xout_is_f32, int w_is_f32, bp_stream_t stream) {
+    if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
+    if (rows <= 0 || cols <= 0 || cols % 4 != 0 || cols > 8192) return BP_ERR_SHAPE;
+    if (x0 == nullptr || gamma == nullptr || beta == nullptr || z == nullptr) return BP_ERR_SHAPE;
+    if (!aligned16(x0) || !aligned16(gamma) || !aligned16(beta) || !aligned16(z) ||
+        (x1 != nullptr && !aligned16(x1)) || (x_out != nullptr && !aligned16(x_out)))
+        return BP_ERR_SHAPE;
+    if (!(isfinite(epsilon) && epsilon >= 0.f)) return BP_ERR_SCALE;
+    // one residual dtype: when both x1 and x_out exist they must agree (reference ln_api.cpp:99-102)
+    if (x1 != nullptr && x_out != nullptr && (x1_is_f32 != 0) != (xout_is_f32 != 0)) return BP_ERR_DTYPE;
+    bp::LnParams p{};
+    p.x0 = x0; p.x1 = x1; p.gamma = gamma; p.beta = beta; p.z = z; p.x_out = x_out;
+    p.rows = rows; p.cols = cols; p.eps = epsilon;
+    p.x1_f32 = x1_is_f32 ? 1 : 0; p.xo_f32 = xout_is_f32 ? 1 : 0; p.w_f32 = w_is_f32 ? 1 : 0;
+    hipError_t e = bp::launch_add_layer_norm(p, dtype, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
+}
+
 }  // extern "C"

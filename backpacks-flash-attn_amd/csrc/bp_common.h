@@ -29,6 +29,13 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 #define BP_DEV __device__ __forceinline__
 
+// Bit casts take their operand BY VALUE on purpose: hipcc / clang 22 (ROCm 7.2) evaluates
+// `__builtin_bit_cast(float, vec[i])` -- an ext-vector ELEMENT lvalue as operand -- as a cast of
+// element 0 whatever i is (seen in the IR as a splat; it silently broke a permlane exchange and a
+// residual load before the parity tests caught it).  Passing through a by-value parameter is safe.
+BP_DEV float as_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
+BP_DEV uint32_t as_u32(float f) { return __builtin_bit_cast(uint32_t, f); }
+
 struct BF16 {};
 struct F16 {};
 
@@ -119,15 +126,12 @@ BP_DEV float xhalf(float x) { return __shfl_xor(x, 32); }
 BP_DEV float xhalf_max(float x) { return fmaxf(x, __shfl_xor(x, 32)); }
 BP_DEV float xhalf_sum(float x) { return x + __shfl_xor(x, 32); }
 #else
-// Written as inline asm: with the builtin (__builtin_amdgcn_permlane32_swap) hipcc / ROCm 7.2 drops
-// the second result at -O3 (extractvalue 1 is replaced by extractvalue 0 in the IR: max(r0,r1) -> r0,
-// r0+r1 -> 2*r0; seen in the ISA, caught by the parity tests).  `s_nop 1` covers the
-// "VALU write -> v_permlane read" hazard (2 wait states) that the compiler cannot see inside asm.
 BP_DEV void xhalf_pair(float x, float &a, float &b) {
-    float u = x, w = x;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(u), "+v"(w));
-    a = u;
-    b = w;
+    const uint32_t u = as_u32(x);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const uint32_t r0 = r[0], r1 = r[1];   // by-value copies, see as_f32
+    a = as_f32(r0);
+    b = as_f32(r1);
 }
 BP_DEV float xhalf_max(float x) {
     float a, b;

@@ -51,6 +51,19 @@ struct MixParams {
     float scale_log2e;
 };
 
+struct LnParams {
+    const void *x0;           // (rows, cols) 16-bit
+    const void *x1;           // (rows, cols) residual in, 16-bit or fp32, may be NULL
+    const void *gamma, *beta; // (cols) 16-bit or fp32
+    void *z;                  // (rows, cols) in x0's dtype
+    void *x_out;              // (rows, cols) residual out (x0 + x1), 16-bit or fp32, may be NULL
+    int64_t rows;
+    int cols;
+    int x1_f32, xo_f32, w_f32;
+    float eps;
+};
+
+hipError_t launch_add_layer_norm(const LnParams &p, int dtype, hipStream_t stream);
 hipError_t launch_flash_fwd(const FlashParams &p, int dtype, bool vec, hipStream_t stream);
 // LDS-DMA ring version; needs 16-byte friendly shapes (vec)
 hipError_t launch_flash_fwd_dma(const FlashParams &p, int dtype, hipStream_t stream);

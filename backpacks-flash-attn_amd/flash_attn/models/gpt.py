@@ -15,7 +15,8 @@ from transformers import GPT2Config
 from flash_attn.modules.block import Block
 from flash_attn.modules.embedding import GPT2Embeddings
 from flash_attn.modules.mha import MHA
-from flash_attn.modules.mlp import Mlp
+from flash_attn.modules.mlp import FusedDenseGeluDense, Mlp
+from flash_attn.ops.layer_norm import dropout_add_layer_norm
 
 
 def create_mixer_cls(config, layer_idx=None, process_group=None, device=None, dtype=None):
@@ -41,7 +42,10 @@ def _activation(config):
 def create_mlp_cls(config, layer_idx=None, process_group=None, device=None, dtype=None):
     assert process_group is None
     inner_dim = config.n_inner if config.n_inner is not None else 4 * config.hidden_size
-    # fused_dense_gelu_dense is the same function as Mlp + tanh-GELU (fused epilogue upstream)
+    if getattr(config, 'fused_dense_gelu_dense', False):
+        assert config.activation_function in ('gelu_new', 'gelu_fast'), \
+            'fused_dense_gelu_dense only supports approximate gelu'          # reference gpt.py:75-78
+        return partial(FusedDenseGeluDense, hidden_features=inner_dim, device=device, dtype=dtype)
     return partial(Mlp, hidden_features=inner_dim, activation=_activation(config), device=device,
                    dtype=dtype)
 
@@ -111,8 +115,15 @@ class GPTModel(GPTPreTrainedModel):
     def forward(self, input_ids, position_ids=None, inference_params=None):
         assert inference_params is None, 'KV-cache decoding is out of scope'
         hidden = self.embeddings(input_ids, position_ids=position_ids)
-        residual = self.emb_drop(hidden).float()   # residual stream stays fp32 (gpt.py:231-234)
-        hidden = self.ln_0(residual.to(dtype=self.ln_0.weight.dtype))
+        if self.fused_dropout_add_ln:
+            # one HIP launch: residual (fp32) = hidden, hidden = LN(residual)   (reference gpt.py:236-240)
+            hidden, residual = dropout_add_layer_norm(
+                hidden, None, self.ln_0.weight, self.ln_0.bias,
+                self.emb_drop.p if self.training else 0.0, self.ln_0.eps, prenorm=True,
+                residual_in_fp32=True)
+        else:
+            residual = self.emb_drop(hidden).float()   # residual stream stays fp32 (gpt.py:231-234)
+            hidden = self.ln_0(residual.to(dtype=self.ln_0.weight.dtype))
         for layer in self.layers:
             hidden, residual = layer(hidden, residual)
         return hidden

@@ -21,7 +21,6 @@ class Mlp(nn.Module):
         return y if not self.return_residual else (y, x)
 
 
-# The reference's FusedDenseGeluDense (cuBLASLt epilogue fusion, ops/fused_dense.py:175-404) computes
-# the same function as Mlp with tanh-GELU; on ROCm the linears go to hipBLASLt through torch.
-FusedDenseGeluDense = None
-ParallelFusedDenseGeluDense = None
+from flash_attn.ops.fused_dense import FusedDenseGeluDense  # noqa: E402,F401  (re-export, as upstream)
+
+ParallelFusedDenseGeluDense = None   # tensor parallelism is out of scope

@@ -1,0 +1,82 @@
+"""Fused (dropout +) residual add + LayerNorm -- mirror of the reference's
+flash_attn/ops/layer_norm.py (`dropout_add_layer_norm` :207-217, `layer_norm` :203-204,
+`DropoutAddLayerNorm` :232-252) on the HIP kernel bp_add_layer_norm.
+
+Forward/eval path only: dropout_p must be 0 and rowscale / layerscale (DropPath, LayerScale) are not
+supported -- the Backpack / GPT-2 configs use neither in eval.  Backward recomputes with eager ops
+(fused backward kernels are a "next" row)."""
+import torch
+import torch.nn.functional as F
+from torch.nn import init
+
+import bp_hip
+
+
+class DropoutAddLayerNormFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x0, x1, gamma, beta, epsilon, residual_in_fp32, prenorm):
+        residual_dtype = x1.dtype if x1 is not None else (torch.float32 if residual_in_fp32 else x0.dtype)
+        need_x = prenorm or x1 is not None or residual_dtype != x0.dtype
+        if need_x:
+            z, x = bp_hip.add_layer_norm(x0, x1, gamma, beta, epsilon, residual_dtype=residual_dtype)
+        else:
+            z, x = bp_hip.add_layer_norm(x0, None, gamma, beta, epsilon, return_residual=False), None
+        ctx.save_for_backward(x0, x1, gamma, beta)
+        ctx.eps, ctx.prenorm, ctx.residual_dtype = epsilon, prenorm, residual_dtype
+        return (z, x) if prenorm else z
+
+    @staticmethod
+    def backward(ctx, dz, *args):
+        x0, x1, gamma, beta = ctx.saved_tensors
+        dx = args[0] if args else None
+        with torch.enable_grad():
+            a = x0.detach().requires_grad_()
+            b = x1.detach().requires_grad_() if x1 is not None else None
+            g, bt = gamma.detach().requires_grad_(), beta.detach().requires_grad_()
+            x = a.float() + (b.float() if b is not None else 0.0)
+            z = F.layer_norm(x, (x.shape[-1],), g.float(), bt.float(), ctx.eps).to(x0.dtype)
+            outs, grads = [z], [dz]
+            if ctx.prenorm and dx is not None:
+                outs.append(x.to(ctx.residual_dtype))
+                grads.append(dx)
+            inputs = [a, g, bt] + ([b] if b is not None else [])
+            res = torch.autograd.grad(outs, inputs, grads)
+        da, dg, dbt = res[0], res[1], res[2]
+        db = res[3] if b is not None else None
+        return da, db, dg, dbt, None, None, None
+
+
+def dropout_add_layer_norm(x0, x1, weight, bias, dropout_p, epsilon, rowscale=None, layerscale=None,
+                           prenorm=False, residual_in_fp32=False, return_dropout_mask=False):
+    """z = LayerNorm(dropout(x0) + x1); with prenorm=True returns (z, x0 + x1).
+    residual_in_fp32 only has an effect if x1 is None, otherwise the residual dtype is x1.dtype."""
+    if dropout_p != 0.0 or rowscale is not None or layerscale is not None or return_dropout_mask:
+        raise NotImplementedError('gfx950 build: fused dropout / rowscale / layerscale are not '
+                                  'implemented (eval forward path only)')
+    assert x0.is_cuda and x0.dtype in (torch.float16, torch.bfloat16)
+    return DropoutAddLayerNormFn.apply(x0, x1, weight, bias, epsilon, residual_in_fp32, prenorm)
+
+
+def layer_norm(x, weight, bias, epsilon):
+    return DropoutAddLayerNormFn.apply(x, None, weight, bias, epsilon, False, False)
+
+
+class DropoutAddLayerNorm(torch.nn.Module):
+
+    def __init__(self, hidden_size, prenorm=False, p=0.0, eps=1e-5, residual_in_fp32=False,
+                 device=None, dtype=None):
+        super().__init__()
+        self.prenorm, self.p, self.epsilon, self.residual_in_fp32 = prenorm, p, eps, residual_in_fp32
+        self.weight = torch.nn.Parameter(torch.empty(hidden_size, device=device, dtype=dtype))
+        self.bias = torch.nn.Parameter(torch.empty(hidden_size, device=device, dtype=dtype))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        init.ones_(self.weight)
+        init.zeros_(self.bias)
+
+    def forward(self, x0, x1=None):
+        return dropout_add_layer_norm(x0, x1, self.weight, self.bias, self.p if self.training else 0.0,
+                                      self.epsilon, prenorm=self.prenorm,
+                                      residual_in_fp32=self.residual_in_fp32)

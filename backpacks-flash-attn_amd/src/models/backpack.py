@@ -27,7 +27,8 @@ from transformers import GPT2Config
 import bp_hip
 from flash_attn.models.gpt import GPTModel, GPTPreTrainedModel, _activation, _init_weights, _pad_vocab
 from flash_attn.modules.block import Block
-from flash_attn.modules.mlp import Mlp
+from flash_attn.modules.mlp import FusedDenseGeluDense, Mlp
+from flash_attn.ops.layer_norm import dropout_add_layer_norm
 
 
 class BackpackConfig(GPT2Config):
@@ -46,6 +47,10 @@ def create_content_mlp_cls(config, layer_idx=None, expand_out=False, process_gro
     if getattr(config, 'shrink_final_inner', None):
         inner_dim = config.hidden_size
     outer_dim = config.num_content_vectors * config.hidden_size if expand_out else config.hidden_size
+    if getattr(config, 'fused_dense_gelu_dense', False):
+        assert config.activation_function in ('gelu_new', 'gelu_fast')      # reference :60-62
+        return partial(FusedDenseGeluDense, hidden_features=inner_dim, out_features=outer_dim,
+                       device=device, dtype=dtype)
     return partial(Mlp, hidden_features=inner_dim, out_features=outer_dim,
                    activation=_activation(config), device=device, dtype=dtype)
 
@@ -137,8 +142,14 @@ class BackpackContentModule(nn.Module):
 
     def forward(self, input_ids, position_ids=None, inference_params=None):
         hidden = self.embeddings.word_embeddings(input_ids)          # no positions (reference :258)
-        residual = self.emb_drop(hidden).float()
-        hidden = self.ln_0(residual.to(dtype=self.ln_0.weight.dtype))
+        if self.fused_dropout_add_ln:
+            hidden, residual = dropout_add_layer_norm(                # reference :263-268
+                hidden, None, self.ln_0.weight, self.ln_0.bias,
+                self.emb_drop.p if self.training else 0.0, self.ln_0.eps, prenorm=True,
+                residual_in_fp32=True)
+        else:
+            residual = self.emb_drop(hidden).float()
+            hidden = self.ln_0(residual.to(dtype=self.ln_0.weight.dtype))
         for layer in self.layers:
             hidden, residual = layer(hidden, residual)
         hidden = self.final_mlp(hidden)                               # (B, S, k*d)

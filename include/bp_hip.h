@@ -133,6 +133,25 @@ int bp_sense_mix(const void *qk, const void *content, void *out, float *lse_ws, 
                  int64_t o_batch_stride, int64_t o_row_stride,
                  float softmax_scale, int dtype, bp_stream_t stream);
 
+/*
+ * bp_add_layer_norm -- fused residual add + LayerNorm forward (eval path):
+ *   x = x0 + x1 ;  z = (x - mean) * rsqrt(var + eps) * gamma + beta     (fp32 math)
+ * Replaces dropout_layer_norm.dropout_add_ln_fwd with dropout_p = 0 and no rowscale / colscale /
+ * subset (reference csrc/layer_norm/ln_api.cpp:83-254, called from
+ * flash_attn/ops/layer_norm.py:9-25 by Block.forward, flash_attn/modules/block.py:83-104, and by
+ * GPTModel.forward, flash_attn/models/gpt.py:236-240).
+ *   x0       (rows, cols) contiguous, dtype `dtype` (fp16 / bf16)
+ *   x1       residual in, (rows, cols) contiguous, fp32 if x1_is_f32 else `dtype`; may be NULL
+ *   gamma, beta  (cols), fp32 if w_is_f32 else `dtype`
+ *   z        (rows, cols) in `dtype` (the reference's otype = itype, ln_api.cpp:104)
+ *   x_out    residual out = x0 + x1 rounded to its dtype (fp32 if xout_is_f32 else `dtype`); may be
+ *            NULL.  z is computed from the unrounded fp32 sum (ln_fwd_kernels.cuh:131-133).
+ * cols must be a multiple of 4 and <= 8192; all pointers 16-byte aligned.
+ */
+int bp_add_layer_norm(const void *x0, const void *x1, const void *gamma, const void *beta, void *z,
+                      void *x_out, int64_t rows, int cols, float epsilon, int dtype, int x1_is_f32,
+                      int xout_is_f32, int w_is_f32, bp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,7 @@ Reference anchors (paths relative to the reference repo):
   * GPT-2 trunk                   flash_attn/models/gpt.py:224-246, modules/block.py:70-106
   * per-layer softmax scale       flash_attn/models/gpt.py:47-50
   * LM head                       training/src/models/backpack.py:342-351
+  * fused add + LayerNorm         flash_attn/ops/layer_norm.py:207-217, csrc/layer_norm/ln_fwd_kernels.cuh:116-175
 """
 import math
 
@@ -156,6 +157,19 @@ def sense_mix_from_qk_fp32(qk, content, softmax_scale=None):
     qk (B,S,2,k,d_k), content (B,k,S,dout) or its (B,S,k,dout) storage -> (B,S,dout) fp32."""
     alpha = sense_alpha_from_qk(qk.float(), softmax_scale)
     return sense_mix(alpha, content.float())
+
+
+def add_layer_norm_fp32(x0, x1, gamma, beta, eps, residual_dtype=None):
+    """Eval-mode dropout_add_layer_norm (flash_attn/ops/layer_norm.py:207-217; kernel
+    csrc/layer_norm/ln_fwd_kernels.cuh:116-175): x = x0 + x1 in fp32, z = LN(x) in fp32 from the
+    UNROUNDED sum, z stored in x0's dtype, x in the residual dtype (x1's, else `residual_dtype`).
+    Statistics as the kernel: mean, then centred sum of squares / n, rsqrt(var + eps)."""
+    x = x0.float() + (x1.float() if x1 is not None else 0.0)
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    z = (x - mu) * torch.rsqrt(var + eps) * gamma.float() + beta.float()
+    rdt = x1.dtype if x1 is not None else (residual_dtype or x0.dtype)
+    return z.to(x0.dtype), x.to(rdt)
 
 
 # --------------------------------------------------------------------------------------

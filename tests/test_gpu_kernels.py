@@ -272,3 +272,49 @@ def test_errors_are_loud():
         bp.flash_fwd(big, big, big, torch.empty_like(big), cu, cu, 64, 64, 0.1, True)
     with pytest.raises(RuntimeError):
         bp.flash_fwd(q.cpu(), q.cpu(), q.cpu(), out.cpu(), cu.cpu(), cu.cpu(), 64, 64, 0.125, True)
+
+
+# ---------------------------------------------------------------------------------------------
+# fused residual add + LayerNorm
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('cols', [768, 384, 640, 64, 1024, 2560, 8192, 100])
+@pytest.mark.parametrize('mode', ['fp32res', 'nores_fp32out', 'same_dtype', 'z_only'])
+def test_add_layer_norm(cols, dtype, mode):
+    bp = _bp()
+    torch.manual_seed(cols)
+    rows = 37 if cols > 1024 else 203
+    x0 = (torch.randn(rows, cols) * 2).to(dtype)
+    w = (1 + 0.2 * torch.randn(cols)).to(dtype)
+    b = (0.1 * torch.randn(cols)).to(dtype)
+    x1 = None
+    rdt = None
+    if mode == 'fp32res':
+        x1 = torch.randn(rows, cols) * 3
+    elif mode == 'same_dtype':
+        x1 = (torch.randn(rows, cols) * 3).to(dtype)
+    elif mode == 'nores_fp32out':
+        rdt = torch.float32
+    z_ref, x_ref = R.add_layer_norm_fp32(x0, x1, w, b, 1e-5, residual_dtype=rdt)
+    z32 = R.add_layer_norm_fp32(x0.float(), x1.float() if x1 is not None else None, w.float(), b.float(), 1e-5)[0]
+    dev = lambda t: t.to(DEV) if t is not None else None
+    if mode == 'z_only':
+        z = bp.add_layer_norm(dev(x0), None, dev(w), dev(b), 1e-5, return_residual=False)
+        x = None
+    else:
+        z, x = bp.add_layer_norm(dev(x0), dev(x1), dev(w), dev(b), 1e-5, residual_dtype=rdt)
+    # eager same-dtype baseline: what torch does on the 16-bit tensors (unfused reference path)
+    res = (x0 + x1) if x1 is not None else x0
+    eager = torch.nn.functional.layer_norm(res.to(dtype), (cols,), w, b, 1e-5)
+    rel_check(z, z32, eager, f'ln {cols} {dtype} {mode}', atol=2e-3 if dtype == torch.float16 else 2e-2)
+    if x is not None:
+        assert x.dtype == x_ref.dtype
+        assert torch.equal(x.cpu(), x_ref), 'residual stream must be the exactly rounded fp32 sum'
+
+
+def test_add_layer_norm_rejects_bad_shapes():
+    bp = _bp()
+    x = torch.randn(4, 66, device=DEV).bfloat16()      # cols % 4 != 0
+    w = torch.ones(66, device=DEV).bfloat16()
+    with pytest.raises(RuntimeError):
+        bp.add_layer_norm(x, None, w, w, 1e-5)

@@ -10,21 +10,25 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
 
-def _nano(use_flash=True, dtype=torch.bfloat16):
+def _nano(use_flash=True, dtype=torch.bfloat16, fused=False):
     from src.models.backpack import BackpackConfig, BackpackLMHeadModel
     g = load_golden('g4_nano_model.npz')
     sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd/')}
     cfg = BackpackConfig(n_embd=64, n_head=2, n_layer=2, num_content_vectors=4, vocab_size=96,
                          n_positions=32, scale_attn_by_inverse_layer_idx=True, resid_pdrop=0.0,
                          embd_pdrop=0.0, attn_pdrop=0.0, use_flash_attn=use_flash,
+                         fused_dropout_add_ln=fused, fused_dense_gelu_dense=fused, fused_bias_fc=fused,
                          pad_vocab_size_multiple=8)
     model = BackpackLMHeadModel(cfg)
     model.load_state_dict(sd)
     return g, sd, model.to(DEV, dtype).eval()
 
 
-def test_nano_model_hip_vs_golden():
-    g, sd, model = _nano()
+@pytest.mark.parametrize('fused', [False, True])
+def test_nano_model_hip_vs_golden(fused):
+    """fused=True is the reference's backpack-small-flash flag set (fused_dropout_add_ln,
+    fused_dense_gelu_dense, fused_bias_fc): add+LN in one HIP launch, GELU in the GEMM epilogue."""
+    g, sd, model = _nano(fused=fused)
     ids = torch.from_numpy(g['ids']).to(DEV)
     with torch.no_grad():
         t = model.transformer
@@ -61,13 +65,15 @@ def test_fused_path_equals_materialised_alpha_path():
     assert (fused - two_step).abs().max().item() < 3e-2
 
 
+@pytest.mark.parametrize('fused', [False, True])
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-def test_micro_config1_forward(dtype):
+def test_micro_config1_forward(dtype, fused):
     """BASELINE config 1 shape (Backpack-Micro, B=4, S=128): HIP 16-bit vs the fp32 CPU oracle."""
     from src.models.backpack import BackpackConfig, BackpackLMHeadModel
     cfg = BackpackConfig(n_embd=384, n_head=6, n_layer=6, num_content_vectors=16, vocab_size=50257,
                          n_positions=128, scale_attn_by_inverse_layer_idx=True, resid_pdrop=0.0,
-                         embd_pdrop=0.0, attn_pdrop=0.0, use_flash_attn=True, pad_vocab_size_multiple=8)
+                         embd_pdrop=0.0, attn_pdrop=0.0, use_flash_attn=True, pad_vocab_size_multiple=8,
+                         fused_dropout_add_ln=fused, fused_dense_gelu_dense=fused, fused_bias_fc=fused)
     torch.manual_seed(0)
     model = BackpackLMHeadModel(cfg).eval()
     with torch.no_grad():   # sharpen attention so the softmax paths matter
