@@ -156,10 +156,24 @@ def _check_qk(qk):
     return qk.shape[0], qk.shape[1], qk.shape[3], qk.shape[4]
 
 
+def _vector_friendly_qk(qk):
+    """The LDS-DMA kernels move 16-byte chunks, i.e. need d_k % 8 == 0.  The Mini k=64 ablation has
+    d_k = 10 (training/configs/experiment/owt/backpack-mini-flash-vecs-64.yaml): zero-pad the head
+    dimension to the next multiple of 8 (zeros add nothing to q.k) instead of falling to the
+    element-wise loader.  Returns (qk', true d_k) -- callers keep scaling by the TRUE d_k."""
+    dk = qk.shape[-1]
+    if dk % 8 == 0:
+        return qk, dk
+    pad = (-dk) % 8
+    return torch.nn.functional.pad(qk, (0, pad)), dk
+
+
 def sense_lse(qk, softmax_scale=None):
     """qk (B,S,2,k,d_k) -> lse (B,k,roundup(S,16)) fp32: log-sum-exp of every causal row."""
     b, s, k, dk = _check_qk(qk)
     scale = softmax_scale or dk ** -0.5
+    qk, _ = _vector_friendly_qk(qk)
+    dk = qk.shape[-1]
     lse = torch.empty((b, k, round_up(s, 16)), dtype=torch.float32, device=qk.device)
     with torch.cuda.device(qk.device):
         code = lib().bp_sense_lse(qk.data_ptr(), lse.data_ptr(), b, s, k, dk,
@@ -182,6 +196,8 @@ def sense_alpha(qk, softmax_scale=None, lse=None):
     diagonal (replaces backpack.py:116-122).  `lse`: optional result of sense_lse(qk)."""
     b, s, k, dk = _check_qk(qk)
     scale = softmax_scale or dk ** -0.5
+    qk, _ = _vector_friendly_qk(qk)
+    dk = qk.shape[-1]
     alpha = torch.empty((b, k, s, s), dtype=qk.dtype, device=qk.device)
     ws, ready = _lse_ws(qk, lse, b, s, k)
     with torch.cuda.device(qk.device):
@@ -206,6 +222,8 @@ def sense_mix(qk, content, softmax_scale=None, out=None, lse=None):
         raise RuntimeError('bp_hip.sense_mix: qk and content dtypes differ')
     dout = content.shape[3]
     scale = softmax_scale or dk ** -0.5
+    qk, _ = _vector_friendly_qk(qk)
+    dk = qk.shape[-1]
     if out is None:
         out = torch.empty((b, s, dout), dtype=qk.dtype, device=qk.device)
     ws, ready = _lse_ws(qk, lse, b, s, k)

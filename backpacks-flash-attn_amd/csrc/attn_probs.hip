@@ -7,9 +7,12 @@
 // `return_attn_probs=True` of the flash interface (flash_attn/flash_attn_interface.py:242-267).
 //
 // One workgroup = 4 waves = 128 query rows of one (batch, head); 64-key K tiles go through
-// double-buffered LDS exactly as in flash_fwd.hip; each wave computes S^T = K Q^T for its 32 rows,
-// exponentiates against the row's final LSE and writes 16-bit P.  Key blocks that lie entirely
-// above the diagonal are not computed, only zero-filled.
+// double-buffered LDS exactly as in flash_fwd.hip; each wave computes S^T = K Q^T for its 32 rows and
+// exponentiates against the row's final LSE.  In S^T layout a lane owns 4-key slivers of ONE row, so
+// storing from registers would touch 32 rows x 16 B per instruction; instead every wave transposes its
+// 32 x 64 tile through a private 4 KB LDS scratch (XOR-swizzled 8-byte units) and writes whole
+// 128-byte row segments: 8 rows x 128 B per store instruction.  Key blocks entirely above the
+// diagonal are not computed, only zero-filled with the same full-line stores.
 #include "bp_common.h"
 #include "bp_kernels.h"
 
@@ -28,7 +31,7 @@ template <class ET, int KD, bool VEC>
 __global__ __launch_bounds__(256) void attn_probs_kernel(const ProbsParams p) {
     using C = ProbsCfg<KD>;
     using E = Elem<ET>;
-    __shared__ __attribute__((aligned(16))) char smem[2 * C::KTILE];
+    __shared__ __attribute__((aligned(16))) char smem[2 * C::KTILE + 4 * 4096];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -113,6 +116,29 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const ProbsParams p) {
         }
     };
 
+    // ---- full-line path: tile -> wave-private LDS scratch -> 16-byte row-contiguous stores -------------
+    // scratch image: [32 rows][16 units of 8 B], unit u of row r stored at u ^ (r & 15)
+    char *scratch = smem + 2 * C::KTILE + wave * 4096;
+    const bool fast_rows = p.p_vec16 != 0;
+    const int rd_row = lane >> 3;          // + 8 * j : row this lane stores in pass j
+    const int rd_chunk = lane & 7;         // 16-byte chunk of the 128-byte row segment
+    auto store_tile_rows = [&](int kb, bool zeros) {
+        // whole 64-key tile inside the row: rows q0 .. q0+31, byte columns kb*128 .. +127
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = rd_row + 8 * j;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (!zeros) {
+                const int u0 = (2 * rd_chunk) ^ (r & 15), u1 = (2 * rd_chunk + 1) ^ (r & 15);
+                const u32x2 a = *reinterpret_cast<const u32x2 *>(scratch + r * 128 + u0 * 8);
+                const u32x2 b = *reinterpret_cast<const u32x2 *>(scratch + r * 128 + u1 * 8);
+                v = u32x4{a[0], a[1], b[0], b[1]};
+            }
+            if (q0 + r < p.sq)
+                *reinterpret_cast<u32x4 *>(pg + (int64_t)(q0 + r) * p.p_rs + kb * C::BN + rd_chunk * 8) = v;
+        }
+    };
+
     if (nkb > 0) {
         fetch(0);
         stash(0);
@@ -122,7 +148,40 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const ProbsParams p) {
         const int cur = kb & 1;
         if (kb + 1 < nkb) fetch(kb + 1);
         const bool dead_block = p.causal && kb * C::BN > q0 + 31;   // all keys above my 32 rows
-        if (wave_has_rows) {
+        const bool full_tile = fast_rows && (kb * C::BN + C::BN <= p.sk);
+        if (wave_has_rows && full_tile) {
+            if (dead_block) {
+                store_tile_rows(kb, true);
+            } else {
+                const char *kbuf = smem + cur * C::KTILE;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    f32x16 st;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+                    for (int s = 0; s < KD; ++s) {
+                        const u32x4 a = lds_read_16B(kbuf, k_lane_off + kk * 32 * C::KROW + s * 32);
+                        st = E::mfma(a, qf[s], st);
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float e[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int key = kb * C::BN + kk * 32 + 8 * g + 4 * hh + i;
+                            e[i] = fast_exp2(fmaf(st[4 * g + i], c2, -lse2));
+                            if (p.causal && key > my_q) e[i] = 0.f;
+                        }
+                        // my 4 keys = 8-byte unit (kk*8 + 2*g + hh) of row l31
+                        const int unit = (kk * 8 + 2 * g + hh) ^ (l31 & 15);
+                        u32x2 w = {E::pack2(e[0], e[1]), E::pack2(e[2], e[3])};
+                        *reinterpret_cast<u32x2 *>(scratch + l31 * 128 + unit * 8) = w;
+                    }
+                }
+                store_tile_rows(kb, false);   // same wave wrote the scratch: LDS ops complete in order
+            }
+        } else if (wave_has_rows) {
             if (dead_block) {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
@@ -158,7 +217,10 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const ProbsParams p) {
     }
     // key blocks past the workgroup's causal range: zeros only
     if (wave_has_rows) {
-        for (int kb = nkb; kb < nkb_all; ++kb)
+        int kb = nkb;
+        if (fast_rows)
+            for (; kb < nkb_all && kb * C::BN + C::BN <= p.sk; ++kb) store_tile_rows(kb, true);
+        for (; kb < nkb_all; ++kb)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll

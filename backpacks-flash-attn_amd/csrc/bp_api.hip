@@ -118,6 +118,7 @@ int bp_attn_probs(const void *q, const void *k, const float *softmax_lse, void *
     p.causal = is_causal ? 1 : 0;
     p.p_vec = ((reinterpret_cast<uintptr_t>(probs) & 7u) == 0 && (p_batch_stride & 3) == 0 &&
                (p_head_stride & 3) == 0 && (p_row_stride & 3) == 0) ? 1 : 0;
+    p.p_vec16 = (aligned16(probs) && mult8(p_batch_stride) && mult8(p_head_stride) && mult8(p_row_stride)) ? 1 : 0;
     p.scale_log2e = softmax_scale * bp::kLog2e;
     const bool vec = (head_dim % 8 == 0) && aligned16(q) && aligned16(k) && mult8(q_batch_stride) &&
                      mult8(q_row_stride) && mult8(q_head_stride) && mult8(k_batch_stride) &&

@@ -32,6 +32,7 @@ struct ProbsParams {
     int b, h, d, sq, sk;
     int causal;
     int p_vec;                // 1: 8-byte stores into P are aligned
+    int p_vec16;              // 1: 16-byte stores at multiples of 8 keys are aligned (full-line path)
     float scale_log2e;
 };
 

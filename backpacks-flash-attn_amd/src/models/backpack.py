@@ -29,6 +29,7 @@ from flash_attn.models.gpt import GPTModel, GPTPreTrainedModel, _activation, _in
 from flash_attn.modules.block import Block
 from flash_attn.modules.mlp import FusedDenseGeluDense, Mlp
 from flash_attn.ops.layer_norm import dropout_add_layer_norm
+from src.utils.generation import GenerationMixin
 
 
 class BackpackConfig(GPT2Config):
@@ -188,7 +189,7 @@ class BackpackModel(GPTPreTrainedModel):
         return torch.sum(contextualization @ content, dim=1)                       # (B,S,d)
 
 
-class BackpackLMHeadModel(BackpackPreTrainedModel):
+class BackpackLMHeadModel(BackpackPreTrainedModel, GenerationMixin):
 
     def __init__(self, config: BackpackConfig, process_group=None, device=None, dtype=None):
         super().__init__(config)

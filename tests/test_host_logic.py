@@ -151,3 +151,32 @@ def test_hip_branch_never_falls_back():
         fai._flash_attn_forward(qkv[0, :, 0], qkv[0, :, 1], qkv[0, :, 2], qkv[0, :, 0].clone(),
                                 None, None, 8, 8, 0.1, 0.2, True, False)
     assert FlashMHA(64, 2).head_dim == 32
+
+
+def test_generation_and_checkpoint_roundtrip(tmp_path):
+    """GenerationMixin (training/src/utils/generation.py:80-92) and the Lightning-checkpoint loader
+    (training/src/utils/checkpoint.py:68-76) on the eager CPU path."""
+    from src.utils.checkpoint import load_backpack_checkpoint, remove_model_prefix
+    from src.utils.generation import greedy_decode
+    torch.manual_seed(0)
+    model = BackpackLMHeadModel(nano_config()).eval()
+    ckpt = {'state_dict': {'model.' + k: v for k, v in model.state_dict().items()}, 'epoch': 3}
+    path = tmp_path / 'last.ckpt'
+    torch.save(ckpt, path)
+    other = BackpackLMHeadModel(nano_config()).eval()
+    res = load_backpack_checkpoint(other, path)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert set(remove_model_prefix(ckpt)) == set(model.state_dict())
+    ids = torch.randint(0, 96, (1, 5), generator=torch.Generator().manual_seed(1))
+    seq = model.generate(ids, max_length=9)
+    assert seq.shape == (1, 9) and torch.equal(seq[:, :5], ids)
+    assert torch.equal(other.generate(ids, max_length=9), seq)          # same weights, same greedy path
+    # each new token is the argmax of the full forward on the prefix (no cache, as upstream)
+    with torch.no_grad():
+        for t in range(5, 9):
+            assert seq[0, t] == model(seq[:, :t]).logits[0, -1].argmax()
+    out = model.generate(ids, max_length=7, return_dict_in_generate=True, output_scores=True)
+    assert out.sequences.shape == (1, 7) and len(out.scores) == 1
+    assert model.sample(ids, max_length=8).shape == (1, 8)
+    batch = greedy_decode(torch.cat([ids, ids]), model, 8).sequences
+    assert torch.equal(batch[0], batch[1]) and torch.equal(batch[0], seq[0, :8])
