@@ -30,6 +30,11 @@ inline bool env_is(const char *name, const char *value) {
 // views) the register-staged kernel with its element-wise loader.
 inline hipError_t dispatch_flash(const bp::FlashParams &p, int dtype, bool vec, hipStream_t st) {
     static const bool force_staged = env_is("BP_FLASH_IMPL", "staged");
+    static const bool use_dma2 = env_is("BP_FLASH_IMPL", "dma2");
+    if (vec && use_dma2) {
+        hipError_t e = bp::launch_flash_fwd_dma2(p, dtype, st);
+        if (e != hipErrorNotSupported) return e;
+    }
     if (vec && !force_staged) return bp::launch_flash_fwd_dma(p, dtype, st);
     return bp::launch_flash_fwd(p, dtype, vec, st);
 }
@@ -91,6 +96,7 @@ int bp_flash_fwd(const void *q, const void *k, const void *v, void *out, float *
     if (v != nullptr)
         vec = vec && aligned16(v) && aligned16(out) && mult8(v_row_stride) && mult8(v_head_stride) &&
               mult8(o_row_stride) && mult8(o_head_stride);
+    if (const char *pe = getenv("BP_PROF_PTR")) p.prof = reinterpret_cast<unsigned long long *>(strtoull(pe, nullptr, 0));
     hipError_t e = dispatch_flash(p, dtype, vec, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
 }

@@ -170,6 +170,15 @@ __global__ __launch_bounds__(256, BP_FLASH_MINWAVES) void flash_fwd_dma_kernel(c
         for (int n = 0; n < NV; ++n) v_read_off[n] = v_lds_off<NV>(v_row_lane, n * 4 + v_ch_lane) + (lane & 1) * 8;
     }
 
+#ifdef BP_PROFILE_PHASES
+    // debug build: per-wave cycle stamps (s_memtime) summed per phase into p.lse as raw uint64 pairs
+    unsigned long long ph[5] = {0, 0, 0, 0, 0};
+    unsigned long long t_prev = __builtin_readcyclecounter();
+    const unsigned long long t_start = t_prev;
+#define BP_STAMP(i) { unsigned long long t_now = __builtin_readcyclecounter(); ph[i] += t_now - t_prev; t_prev = t_now; }
+#else
+#define BP_STAMP(i)
+#endif
     auto block = [&](int kb, const char *kbuf, const char *vbuf, auto MASKED) {
         constexpr bool kMasked = decltype(MASKED)::value;
         // second 32-key half entirely above my rows?  (only possible on a masked tile)
@@ -203,6 +212,7 @@ __global__ __launch_bounds__(256, BP_FLASH_MINWAVES) void flash_fwd_dma_kernel(c
                 }
             }
         }
+        BP_STAMP(1)
         // row max: four independent chains (short dependency depth), then the other half-wave
         // (plain fmaxf chains: hipcc fuses each pair into one v_max3_f32 and knows the MFMA->VALU
         //  read hazard, which an inline-asm v_max3 on fresh MFMA results would bypass)
@@ -239,6 +249,7 @@ __global__ __launch_bounds__(256, BP_FLASH_MINWAVES) void flash_fwd_dma_kernel(c
             }
         const float rs = rs2[0] + rs2[1];
         l_run = l_run * alpha + rs;
+        BP_STAMP(2)
 #ifdef BP_ABL_NOPV
         asm volatile("" ::"v"(st[0][0]), "v"(st[0][15]), "v"(st[1][0]), "v"(st[1][15]), "v"(alpha));
         if (false) {
@@ -300,6 +311,7 @@ __global__ __launch_bounds__(256, BP_FLASH_MINWAVES) void flash_fwd_dma_kernel(c
 #ifndef BP_ABL_NODMA
         if (kb + C::NSTAGE - 1 < nkb) issue(kb + C::NSTAGE - 1);
 #endif
+        BP_STAMP(0)
         const bool active = wave_has_rows && !(p.causal && kb * C::BN > q0 + 31);
         if (active) {
             const char *kbuf = smem + (kb % C::NSTAGE) * C::STAGE;
@@ -308,7 +320,19 @@ __global__ __launch_bounds__(256, BP_FLASH_MINWAVES) void flash_fwd_dma_kernel(c
             if (need_mask) block(kb, kbuf, vbuf, std::true_type{});
             else block(kb, kbuf, vbuf, std::false_type{});
         }
+        BP_STAMP(4)
     }
+#ifdef BP_PROFILE_PHASES
+    if (lane == 0 && p.o_bs == -12345) {   // never true: keeps the stamps alive without touching outputs
+        p.lse[0] = (float)(ph[0] + ph[1] + ph[2] + ph[3] + ph[4]);
+    }
+    if (lane == 0 && p.prof != nullptr) {
+        const int64_t w = ((int64_t)blockIdx.x * 4 + wave) * 8;
+        p.prof[w + 0] = ph[0]; p.prof[w + 1] = ph[1]; p.prof[w + 2] = ph[2]; p.prof[w + 3] = ph[3];
+        p.prof[w + 4] = ph[4]; p.prof[w + 5] = __builtin_readcyclecounter() - t_start; p.prof[w + 6] = nkb;
+        p.prof[w + 7] = qt;
+    }
+#endif
 
     if (!wave_has_rows) return;
     const float l_tot = xhalf_sum(l_run);

@@ -153,10 +153,21 @@ def cpu_baseline(model_name, seq, budget_s=15.0, threads=None):
             if time.perf_counter() - t_start > 2 * budget_s:
                 break
     mean = sum(times) / len(times)
+    # BASELINE.json configs[0] exactly (the reference's own CPU-runnable case): Micro, B=4, S=128, fp32
+    mcfg = R.make_config('micro', n_positions=128)
+    msd = R.init_state_dict(mcfg, seed=0)
+    mids = torch.randint(0, 50257, (4, 128), generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        R.backpack_forward(msd, mcfg, mids)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            R.backpack_forward(msd, mcfg, mids)
+        micro = (time.perf_counter() - t0) / 5
     return dict(value=b * seq / mean, unit='tokens/s', cores=cores, kind='port',
                 sample=f'oracle/ref_cpu.backpack_forward (reference eager path), Backpack-{model_name} '
                        f'fp32, batch {b} x seq {seq}, {len(times)} timed forwards after 1 warm-up, '
-                       f'mean {mean:.3f} s/forward, torch {torch.get_num_threads()} threads')
+                       f'mean {mean:.3f} s/forward, torch {torch.get_num_threads()} threads',
+                config1_micro_b4_s128_tokens_per_s=round(4 * 128 / micro, 1))
 
 
 def main():

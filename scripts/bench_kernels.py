@@ -40,6 +40,7 @@ def main():
     ap.add_argument('--d', type=int, default=768)
     ap.add_argument('--dtype', default='bf16')
     ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--noncausal', action='store_true')
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == 'bf16' else torch.float16
     dev = 'cuda'
@@ -52,8 +53,9 @@ def main():
         qkv = torch.randn(B * S, 3, H, D, device=dev).to(dt)
         out = torch.empty_like(qkv[:, 0])
         cu = torch.arange(0, (B + 1) * S, S, dtype=torch.int32, device=dev)
-        ms = timeit(lambda: bp_hip.flash_fwd(qkv[:, 0], qkv[:, 1], qkv[:, 2], out, cu, cu, S, S, D ** -0.5, True), a.iters)
-        fl, by = 4 * pairs * D * H * B, 8 * S * D * H * B
+        causal = not a.noncausal
+        ms = timeit(lambda: bp_hip.flash_fwd(qkv[:, 0], qkv[:, 1], qkv[:, 2], out, cu, cu, S, S, D ** -0.5, causal), a.iters)
+        fl, by = 4 * (pairs if causal else S * S) * D * H * B, 8 * S * D * H * B
         res.append(dict(kernel='flash_fwd', ms=ms, tflops=fl / ms / 1e9, gbps=by / ms / 1e6))
     if 'lse' in which or 'mix' in which or 'alpha' in which:
         qk = torch.randn(B, S, 2, K, d // K, device=dev).to(dt)

@@ -318,3 +318,76 @@ def test_add_layer_norm_rejects_bad_shapes():
     w = torch.ones(66, device=DEV).bfloat16()
     with pytest.raises(RuntimeError):
         bp.add_layer_norm(x, None, w, w, 1e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+# callers either side of the path: the intervention scripts edit `content`
+# (or, equivalently, columns of alpha) and redo sum_l alpha_l @ C_l -- the fused kernel takes their
+# tensors as they are: (B,k,S,d_out)-contiguous content, vocab-sized d_out.
+# ---------------------------------------------------------------------------------------------
+def test_sense_mix_intervention_shapes():
+    """training/src/models/intervened_models.py:97-101 (content * per-(b,s,l) weights, a fresh
+    (B,k,S,d) tensor) and :153-161 (content logits with a vocab-sized trailing dim)."""
+    bp = _bp()
+    torch.manual_seed(21)
+    b, s, k, dk, d, vocab = 2, 96, 16, 24, 384, 1000
+    qk = (torch.randn(b, s, 2, k, dk) * 1.3).bfloat16()
+    content = torch.randn(b, s, k * d).bfloat16().reshape(b, s, k, d).transpose(1, 2)      # model's view
+    weights = torch.rand(b, s, k)                                                          # soft mask
+    weighted = (content * weights.transpose(1, 2).unsqueeze(3).bfloat16())                 # (B,k,S,d) contiguous
+    assert weighted.is_contiguous()
+    want = R.sense_mix_from_qk_fp32(qk, weighted)
+    eager = R.sense_mix(R.sense_alpha_from_qk(qk), weighted)
+    out = bp.sense_mix(qk.to(DEV), weighted.to(DEV).transpose(1, 2))                        # strided view, no copy
+    rel_check(out, want, eager, 'mix weighted content')
+    # scaling a column of alpha == scaling that key's content row (test_genderbias.py:71-78)
+    alpha = R.sense_alpha_from_qk(qk.float())
+    col = torch.ones(b, k, 1, s)
+    col[:, 3, :, 40] = 0.25
+    want2 = R.sense_mix(alpha * col, content.float())
+    scaled = content.float() * col.squeeze(2).unsqueeze(3)
+    out2 = bp.sense_mix(qk.to(DEV), scaled.bfloat16().to(DEV).transpose(1, 2))
+    assert (out2.float().cpu() - want2).abs().max().item() < 0.06
+    # vocab-sized trailing dimension
+    lm_w = (torch.randn(vocab, d) * 0.05).bfloat16()
+    logits_c = (content.float() @ lm_w.float().t()).bfloat16()                               # (B,k,S,V)
+    want3 = R.sense_mix_from_qk_fp32(qk, logits_c)
+    eager3 = R.sense_mix(R.sense_alpha_from_qk(qk), logits_c)
+    out3 = bp.sense_mix(qk.to(DEV), logits_c.to(DEV).transpose(1, 2))
+    assert out3.shape == (b, s, vocab)
+    rel_check(out3, want3, eager3, 'mix vocab-sized')
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE config 5 shape (S = 4096, fp16): oracle on a subset of query rows (full key range)
+# ---------------------------------------------------------------------------------------------
+def test_flash_fwd_seq4096_fp16_rows():
+    bp = _bp()
+    torch.manual_seed(40)
+    s, h, d = 4096, 12, 64
+    qkv = torch.randn(1, s, 3, h, d).half()
+    out, lse = run_flash_fixed(qkv.to(DEV), d ** -0.5, True)
+    rows = torch.tensor([0, 1, 63, 64, 127, 128, 2047, 2048, 4000, 4095])
+    q, k, v = qkv[0, :, 0].float(), qkv[0, :, 1].float(), qkv[0, :, 2].float()
+    scores = torch.einsum('thd,shd->hts', q[rows], k) * d ** -0.5
+    mask = torch.arange(s)[None, :] > rows[:, None]
+    scores = scores.masked_fill(mask[None], float('-inf'))
+    want = torch.einsum('hts,shd->thd', torch.softmax(scores, -1), v)
+    assert (out[0, rows].float().cpu() - want).abs().max().item() < 4e-3
+    assert (lse[0][:, rows].cpu() - torch.logsumexp(scores, -1)).abs().max().item() < 2e-3
+
+
+def test_sense_mix_seq4096_fp16_rows():
+    bp = _bp()
+    torch.manual_seed(41)
+    s, k, dk, d = 4096, 16, 48, 768
+    qk = torch.randn(1, s, 2, k, dk).half()
+    c = torch.randn(1, s, k, d).half()
+    out = bp.sense_mix(qk.to(DEV), c.to(DEV))
+    rows = torch.tensor([0, 31, 32, 255, 256, 1023, 1024, 3000, 4095])
+    q, kk = qk[0, :, 0].float(), qk[0, :, 1].float()
+    scores = torch.einsum('tld,sld->lts', q[rows], kk) * dk ** -0.5
+    mask = torch.arange(s)[None, :] > rows[:, None]
+    alpha = torch.softmax(scores.masked_fill(mask[None], float('-inf')), -1)         # (k, rows, S)
+    want = torch.einsum('lts,sld->td', alpha, c[0].float())
+    assert (out[0, rows].float().cpu() - want).abs().max().item() < 2e-2
