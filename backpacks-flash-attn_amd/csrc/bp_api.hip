@@ -238,6 +238,49 @@ int bp_sense_mix(const void *qk, const void *content, void *out, float *lse_ws, 
     return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
 }
 
+int bp_flash_bwd(const void *dout, const void *q, const void *k, const void *v,
+                 const float *softmax_lse, const float *dsum, void *dq, void *dk, void *dv,
+                 const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k,
+                 int batch, int nheads, int head_dim, int max_seqlen_q, int max_seqlen_k,
+                 int64_t do_row_stride, int64_t do_head_stride,
+                 int64_t q_row_stride, int64_t q_head_stride,
+                 int64_t k_row_stride, int64_t k_head_stride,
+                 int64_t v_row_stride, int64_t v_head_stride,
+                 int64_t dq_row_stride, int64_t dq_head_stride,
+                 int64_t dk_row_stride, int64_t dk_head_stride,
+                 int64_t dv_row_stride, int64_t dv_head_stride,
+                 int64_t lse_stride, float softmax_scale, int is_causal, int dtype,
+                 bp_stream_t stream) {
+    if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
+    if (head_dim < 8 || head_dim > 64 || head_dim % 8 != 0) return BP_ERR_HEAD_DIM;
+    if (batch <= 0 || nheads <= 0 || max_seqlen_q <= 0 || max_seqlen_k <= 0) return BP_ERR_SHAPE;
+    if (!dout || !q || !k || !v || !softmax_lse || !dsum || !dq || !dk || !dv) return BP_ERR_SHAPE;
+    if ((cu_seqlens_q == nullptr) != (cu_seqlens_k == nullptr)) return BP_ERR_SHAPE;
+    if (!scale_ok(softmax_scale)) return BP_ERR_SCALE;
+    const void *ptrs[] = {dout, q, k, v, dq, dk, dv, softmax_lse, dsum};
+    for (const void *ptr : ptrs) if (!aligned16(ptr)) return BP_ERR_SHAPE;
+    const int64_t strides[] = {do_row_stride, do_head_stride, q_row_stride, q_head_stride, k_row_stride,
+                               k_head_stride, v_row_stride, v_head_stride, dq_row_stride, dq_head_stride,
+                               dk_row_stride, dk_head_stride, dv_row_stride, dv_head_stride};
+    for (int64_t st : strides) if (!mult8(st)) return BP_ERR_SHAPE;
+    if (lse_stride % 16 != 0) return BP_ERR_SHAPE;
+
+    bp::FlashBwdParams p{};
+    p.q = q; p.k = k; p.v = v; p.dout = dout; p.lse = softmax_lse; p.dsum = dsum;
+    p.dq = dq; p.dk = dk; p.dv = dv; p.cu_q = cu_seqlens_q; p.cu_k = cu_seqlens_k;
+    p.q_rs = q_row_stride; p.q_hs = q_head_stride; p.k_rs = k_row_stride; p.k_hs = k_head_stride;
+    p.v_rs = v_row_stride; p.v_hs = v_head_stride; p.do_rs = do_row_stride; p.do_hs = do_head_stride;
+    p.dq_rs = dq_row_stride; p.dq_hs = dq_head_stride; p.dk_rs = dk_row_stride; p.dk_hs = dk_head_stride;
+    p.dv_rs = dv_row_stride; p.dv_hs = dv_head_stride;
+    p.lse_stride = lse_stride;
+    p.b = batch; p.h = nheads; p.d = head_dim; p.max_sq = max_seqlen_q; p.max_sk = max_seqlen_k;
+    p.causal = is_causal ? 1 : 0;
+    p.scale = softmax_scale;
+    hipError_t e = bp::launch_flash_bwd(p, dtype, static_cast<hipStream_t>(stream));
+    if (e == hipErrorNotSupported) return BP_ERR_HEAD_DIM;
+    return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
+}
+
 int bp_add_layer_norm(const void *x0, const void *x1, const void *gamma, const void *beta, void *z,
                       void *x_out, int64_t rows, int cols, float epsilon, int dtype, int x1_is_f32,
                       int xout_is_f32, int w_is_f32, bp_stream_t stream) {

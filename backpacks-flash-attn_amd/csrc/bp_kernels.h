@@ -23,6 +23,21 @@ struct FlashParams {
     unsigned long long *prof; // BP_PROFILE_PHASES debug builds only (8 u64 per wave), else NULL
 };
 
+struct FlashBwdParams {
+    const void *q, *k, *v, *dout;
+    const float *lse;         // (b, h, lse_stride) from the forward
+    const float *dsum;        // (b, h, lse_stride): D_i = sum_d dO_i[d] * O_i[d]
+    void *dq, *dk, *dv;
+    const int *cu_q, *cu_k;   // NULL: fixed length
+    int64_t q_rs, q_hs, k_rs, k_hs, v_rs, v_hs, do_rs, do_hs;
+    int64_t dq_rs, dq_hs, dk_rs, dk_hs, dv_rs, dv_hs;
+    int64_t lse_stride;
+    int b, h, d, max_sq, max_sk, causal;
+    float scale;
+};
+
+hipError_t launch_flash_bwd(const FlashBwdParams &p, int dtype, hipStream_t stream);
+
 struct ProbsParams {
     const void *q, *k;
     const float *lse;

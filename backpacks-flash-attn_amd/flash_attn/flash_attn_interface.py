@@ -1,11 +1,11 @@
-"""Python API of the fused attention forward -- mirror of the reference's
+"""Python API of the fused attention -- mirror of the reference's
 flash_attn/flash_attn_interface.py (public functions :242-380), with `flash_attn_cuda.fwd`
-(:23-26) replaced by bp_hip.flash_fwd (C ABI bp_flash_fwd, include/bp_hip.h).
+(:23-26) replaced by bp_hip.flash_fwd (C ABI bp_flash_fwd, include/bp_hip.h) and
+`flash_attn_cuda.bwd` (:38-43) by bp_hip.flash_bwd (bp_flash_bwd).
 
-Scope of this build is the FORWARD path: the autograd Functions exist so the
-call sites keep their shape, their backward recomputes attention with differentiable eager ops
-(FA backward kernels are the first "next" row).  Dropout inside the kernel is not implemented;
-`dropout_p` must be 0 as it is in eval / the forward benchmark.
+The HIP backward covers head dims <= 64 (the trunk's 64, the senses' 48/40/24); for larger heads
+the autograd Functions fall back to differentiating an eager recomputation.  Dropout inside the
+kernel is not implemented; `dropout_p` must be 0 as it is in eval / the forward benchmark.
 """
 import torch
 
@@ -39,8 +39,19 @@ def _flash_attn_forward(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, 
     return out, softmax_lse, S_dmask
 
 
+def _flash_attn_backward(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seqlens_k,
+                         max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale, causal, num_splits=0,
+                         generator=None):
+    """Same contract as the reference's helper (:31-47): fills dq, dk, dv in place."""
+    if dropout_p != 0.0:
+        raise RuntimeError('flash_attn (gfx950 build): in-kernel dropout is not implemented')
+    bp_hip.flash_bwd(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seqlens_k,
+                     max_seqlen_q, max_seqlen_k, softmax_scale, causal)
+    return dq, dk, dv
+
+
 def _eager_varlen(q, k, v, cu_q, cu_k, softmax_scale, causal):
-    """Differentiable recomputation used only by backward()."""
+    """Differentiable recomputation, used by backward() for head dims the HIP backward lacks."""
     outs = []
     cu_q, cu_k = cu_q.tolist(), cu_k.tolist()
     for b in range(len(cu_q) - 1):
@@ -55,7 +66,8 @@ def _eager_varlen(q, k, v, cu_q, cu_k, softmax_scale, causal):
 
 
 class _FlashAttnFuncBase(torch.autograd.Function):
-    """forward = HIP kernel; backward = autograd through `_eager_varlen` (see module docstring)."""
+    """forward = HIP kernel; backward = HIP kernels (head dim <= 64) or autograd through
+    `_eager_varlen` (see module docstring)."""
 
     @staticmethod
     def _fwd(ctx, q, k, v, cu_q, cu_k, max_q, max_k, dropout_p, softmax_scale, causal, return_softmax):
@@ -64,10 +76,18 @@ class _FlashAttnFuncBase(torch.autograd.Function):
         out, lse, S = _flash_attn_forward(q, k, v, torch.empty_like(q), cu_q, cu_k, max_q, max_k,
                                           dropout_p, softmax_scale, causal, return_softmax)
         ctx.softmax_scale, ctx.causal = softmax_scale, causal
+        ctx.max_q, ctx.max_k = max_q, max_k
         return out, lse, S
 
     @staticmethod
-    def _bwd(ctx, dout, q, k, v, cu_q, cu_k):
+    def _bwd(ctx, dout, q, k, v, cu_q, cu_k, out=None, lse=None, grads=None):
+        """grads: preallocated (dq, dk, dv) views (the packed Functions hand in slices of one buffer,
+        as the reference does at :77-84)."""
+        if out is not None and bp_hip.flash_bwd_supported(q):
+            dq, dk, dv = grads if grads is not None else (torch.empty_like(q), torch.empty_like(k),
+                                                          torch.empty_like(v))
+            return _flash_attn_backward(dout, q, k, v, out, lse, dq, dk, dv, cu_q, cu_k, ctx.max_q,
+                                        ctx.max_k, 0.0, ctx.softmax_scale, ctx.causal)
         with torch.enable_grad():
             q_, k_, v_ = (t.detach().requires_grad_() for t in (q, k, v))
             out = _eager_varlen(q_, k_, v_, cu_q, cu_k, ctx.softmax_scale, ctx.causal)
@@ -81,14 +101,18 @@ class FlashAttnQKVPackedFunc(_FlashAttnFuncBase):
         out, lse, S = _FlashAttnFuncBase._fwd(ctx, qkv[:, 0], qkv[:, 1], qkv[:, 2], cu_seqlens,
                                               cu_seqlens, max_seqlen, max_seqlen, dropout_p,
                                               softmax_scale, causal, return_softmax)
-        ctx.save_for_backward(qkv, cu_seqlens)
+        ctx.save_for_backward(qkv, cu_seqlens, out, lse)
         return out if not return_softmax else (out, lse, S)
 
     @staticmethod
     def backward(ctx, dout, *args):
-        qkv, cu = ctx.saved_tensors
-        dq, dk, dv = _FlashAttnFuncBase._bwd(ctx, dout, qkv[:, 0], qkv[:, 1], qkv[:, 2], cu, cu)
-        return torch.stack([dq, dk, dv], dim=1), None, None, None, None, None, None
+        qkv, cu, out, lse = ctx.saved_tensors
+        dqkv = torch.empty_like(qkv)
+        dq, dk, dv = _FlashAttnFuncBase._bwd(ctx, dout, qkv[:, 0], qkv[:, 1], qkv[:, 2], cu, cu, out, lse,
+                                             (dqkv[:, 0], dqkv[:, 1], dqkv[:, 2]))
+        if dq.data_ptr() != dqkv.data_ptr():          # eager fallback returned fresh tensors
+            dqkv = torch.stack([dq, dk, dv], dim=1)
+        return dqkv, None, None, None, None, None, None
 
 
 class FlashAttnKVPackedFunc(_FlashAttnFuncBase):
@@ -99,14 +123,18 @@ class FlashAttnKVPackedFunc(_FlashAttnFuncBase):
         out, lse, S = _FlashAttnFuncBase._fwd(ctx, q, kv[:, 0], kv[:, 1], cu_seqlens_q, cu_seqlens_k,
                                               max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale,
                                               causal, return_softmax)
-        ctx.save_for_backward(q, kv, cu_seqlens_q, cu_seqlens_k)
+        ctx.save_for_backward(q, kv, cu_seqlens_q, cu_seqlens_k, out, lse)
         return out if not return_softmax else (out, lse, S)
 
     @staticmethod
     def backward(ctx, dout, *args):
-        q, kv, cu_q, cu_k = ctx.saved_tensors
-        dq, dk, dv = _FlashAttnFuncBase._bwd(ctx, dout, q, kv[:, 0], kv[:, 1], cu_q, cu_k)
-        return dq, torch.stack([dk, dv], dim=1), None, None, None, None, None, None, None, None
+        q, kv, cu_q, cu_k, out, lse = ctx.saved_tensors
+        dkv = torch.empty_like(kv)
+        dq, dk, dv = _FlashAttnFuncBase._bwd(ctx, dout, q, kv[:, 0], kv[:, 1], cu_q, cu_k, out, lse,
+                                             (torch.empty_like(q), dkv[:, 0], dkv[:, 1]))
+        if dk.data_ptr() != dkv.data_ptr():
+            dkv = torch.stack([dk, dv], dim=1)
+        return dq, dkv, None, None, None, None, None, None, None, None
 
 
 class FlashAttnFunc(_FlashAttnFuncBase):
@@ -117,13 +145,13 @@ class FlashAttnFunc(_FlashAttnFuncBase):
         out, lse, S = _FlashAttnFuncBase._fwd(ctx, q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q,
                                               max_seqlen_k, dropout_p, softmax_scale, causal,
                                               return_softmax)
-        ctx.save_for_backward(q, k, v, cu_seqlens_q, cu_seqlens_k)
+        ctx.save_for_backward(q, k, v, cu_seqlens_q, cu_seqlens_k, out, lse)
         return out if not return_softmax else (out, lse, S)
 
     @staticmethod
     def backward(ctx, dout, *args):
-        q, k, v, cu_q, cu_k = ctx.saved_tensors
-        dq, dk, dv = _FlashAttnFuncBase._bwd(ctx, dout, q, k, v, cu_q, cu_k)
+        q, k, v, cu_q, cu_k, out, lse = ctx.saved_tensors
+        dq, dk, dv = _FlashAttnFuncBase._bwd(ctx, dout, q, k, v, cu_q, cu_k, out, lse)
         return dq, dk, dv, None, None, None, None, None, None, None, None
 
 

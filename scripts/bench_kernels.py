@@ -57,6 +57,19 @@ def main():
         ms = timeit(lambda: bp_hip.flash_fwd(qkv[:, 0], qkv[:, 1], qkv[:, 2], out, cu, cu, S, S, D ** -0.5, causal), a.iters)
         fl, by = 4 * (pairs if causal else S * S) * D * H * B, 8 * S * D * H * B
         res.append(dict(kernel='flash_fwd', ms=ms, tflops=fl / ms / 1e9, gbps=by / ms / 1e6))
+    if 'bwd' in which:
+        qkv = torch.randn(B * S, 3, H, D, device=dev).to(dt)
+        dout = torch.randn(B * S, H, D, device=dev).to(dt)
+        out = torch.empty_like(dout)
+        cu = torch.arange(0, (B + 1) * S, S, dtype=torch.int32, device=dev)
+        causal = not a.noncausal
+        lse = bp_hip.flash_fwd(qkv[:, 0], qkv[:, 1], qkv[:, 2], out, cu, cu, S, S, D ** -0.5, causal)
+        dqkv = torch.empty_like(qkv)
+        ms = timeit(lambda: bp_hip.flash_bwd(dout, qkv[:, 0], qkv[:, 1], qkv[:, 2], out, lse, dqkv[:, 0],
+                                             dqkv[:, 1], dqkv[:, 2], cu, cu, S, S, D ** -0.5, causal), a.iters)
+        # 5 matmuls of the textbook backward (S, dP, dV, dK, dQ); this split recomputes S and dP once more
+        fl, by = 10 * (pairs if causal else S * S) * D * H * B, 16 * S * D * H * B
+        res.append(dict(kernel='flash_bwd(dkdv+dq+dsum)', ms=ms, tflops=fl / ms / 1e9, gbps=by / ms / 1e6))
     if 'lse' in which or 'mix' in which or 'alpha' in which:
         qk = torch.randn(B, S, 2, K, d // K, device=dev).to(dt)
     if 'lse' in which:

@@ -334,7 +334,7 @@ def test_sense_mix_intervention_shapes():
     qk = (torch.randn(b, s, 2, k, dk) * 1.3).bfloat16()
     content = torch.randn(b, s, k * d).bfloat16().reshape(b, s, k, d).transpose(1, 2)      # model's view
     weights = torch.rand(b, s, k)                                                          # soft mask
-    weighted = (content * weights.transpose(1, 2).unsqueeze(3).bfloat16())                 # (B,k,S,d) contiguous
+    weighted = (content * weights.transpose(1, 2).unsqueeze(3).bfloat16()).contiguous()   # (B,k,S,d)
     assert weighted.is_contiguous()
     want = R.sense_mix_from_qk_fp32(qk, weighted)
     eager = R.sense_mix(R.sense_alpha_from_qk(qk), weighted)
