@@ -224,7 +224,11 @@ int bp_sense_mix(const void *qk, const void *content, void *out, float *lse_ws, 
     p.b = batch; p.s = seqlen; p.nsenses = nsenses; p.dk = d_k; p.dout = d_out;
     p.n_qtiles = (seqlen + 255) / 256;
     p.n_chunks = (d_out + 255) / 256;
-    p.order = env_is("BP_MIX_ORDER", "grouped") ? 0 : 1;
+    // block -> (group, query tile) order, see sense_mix_dma.hip.  1 (default): heaviest tiles of all
+    // groups first; 2: whole (batch, chunk) groups per XCD in lockstep; 3: 2/3 of the groups in lockstep,
+    // the rest heaviest-first; 0: whole groups per XCD without chunk adjacency.  A/B switch for measurements.
+    p.order = env_is("BP_MIX_ORDER", "grouped") ? 0 : env_is("BP_MIX_ORDER", "lockstep") ? 2
+            : env_is("BP_MIX_ORDER", "hybrid") ? 3 : 1;
     p.scale_log2e = softmax_scale * bp::kLog2e;
     const bool vec_qk = (d_k % 8 == 0) && aligned16(p.q) && aligned16(p.k) && mult8(qk_batch_stride) &&
                         mult8(qk_row_stride) && mult8(qk_sense_stride);

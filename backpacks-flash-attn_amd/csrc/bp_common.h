@@ -86,6 +86,14 @@ BP_DEV u32x4 ld_global_8x2B(const uint16_t *row, int col0, int ncols) {
     return u32x4{w[0], w[1], w[2], w[3]};
 }
 
+// Make a value loaded with a plain global load "arrive" here: the empty asm reads and rewrites the
+// register, so the compiler waits for the load at this point and treats the result as ready afterwards.
+// Without it, operands loaded in a kernel's prologue and first used inside the main loop get their
+// `s_waitcnt vmcnt(0)` INSIDE the loop, which also drains the LDS-DMA queue the compiler cannot see
+// (the next tile, issued just before) and serialises the ring.
+BP_DEV void settle(u32x4 &v) { asm volatile("" : "+v"(v)); }
+BP_DEV void settle(float &v) { asm volatile("" : "+v"(v)); }
+
 // LDS accessors on a byte offset into one shared array.
 BP_DEV u32x4 lds_read_16B(const char *smem, int off) {
     return *reinterpret_cast<const u32x4 *>(smem + off);

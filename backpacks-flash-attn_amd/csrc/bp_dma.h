@@ -32,6 +32,26 @@ BP_DEV void dma16(const uint16_t *g, uint32_t lds_addr) {
         : "memory");
 }
 
+// dma16 for call sites under a per-lane condition: inside divergent control flow the compiler may keep
+// the (uniform) LDS address in a VGPR, which the "s" constraint of the asm rejects.
+BP_DEV void dma16_d(const uint16_t *g, uint32_t lds_addr) {
+    dma16(g, __builtin_amdgcn_readfirstlane(lds_addr));
+}
+
+// 4 bytes per lane (LDS destination = base + lane*4): per-lane scalars such as a row's log-sum-exp.
+BP_DEV void dma4(const void *g, uint32_t lds_addr) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dword %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_addr))
+        : "memory");
+}
+
 // Same, "saddr" form: wave-uniform 64-bit base in SGPRs + per-lane 32-bit BYTE offset.  The per-tile
 // address update then happens on the scalar unit (base += tile stride) and costs no VALU.
 BP_DEV void dma16_s(const uint16_t *uniform_base, uint32_t lane_byte_off, uint32_t lds_addr) {

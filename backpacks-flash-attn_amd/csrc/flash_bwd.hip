@@ -41,12 +41,6 @@ struct BwdCfg {
     static constexpr int R_ROWS_PER_DMA = 1024 / RROW;
 };
 
-// dma16 for call sites under a per-lane condition: inside divergent control flow the compiler may keep
-// the (uniform) LDS address in a VGPR, which the "s" constraint of the asm rejects.
-BP_DEV void dma16_d(const uint16_t *g, uint32_t lds_addr) {
-    dma16(g, __builtin_amdgcn_readfirstlane(lds_addr));
-}
-
 // per-lane DMA descriptor (tile row, first column) of one 1-KiB piece of a row image /
 // transposed-read image
 template <class C>
@@ -141,6 +135,8 @@ __global__ __launch_bounds__(256) void flash_bwd_dkdv_kernel(const FlashBwdParam
             kf[s] = a;
             vf[s] = b;
         }
+#pragma unroll
+        for (int s = 0; s < KD; ++s) { settle(kf[s]); settle(vf[s]); }   // see bp_common.h: no vmcnt(0) in the loop
     }
 
     // ---- DMA descriptors -----------------------------------------------------------------------------
@@ -352,6 +348,9 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashBwdParams 
         const int64_t so = ((int64_t)batch * p.h + head) * p.lse_stride + q;
         lse2 = p.lse[so] * kLog2e;
         dsum = p.dsum[so];
+#pragma unroll
+        for (int s = 0; s < KD; ++s) { settle(qf[s]); settle(dof[s]); }
+        settle(lse2); settle(dsum);
     }
 
     int rr[C::R_DMA], rc[C::R_DMA], tr[C::T_DMA], tc[C::T_DMA];

@@ -100,6 +100,8 @@ __global__ __launch_bounds__(256, BP_FLASH_MINWAVES) void flash_fwd_dma_kernel(c
             if (col < p.d) v = ld_global_16B(row + col);
             qf[s] = v;
         }
+#pragma unroll
+        for (int s = 0; s < KD; ++s) settle(qf[s]);
     }
 
     // ---- per-lane DMA source descriptors: tile row / column of the 16-B chunk this lane moves ----------
@@ -224,7 +226,11 @@ __global__ __launch_bounds__(256, BP_FLASH_MINWAVES) void flash_fwd_dma_kernel(c
             mxc = fmaxf(mxc, st[1][r]);
             mxd = fmaxf(mxd, st[1][8 + r]);
         }
+#ifdef BP_ABL_NOMAX   // ablation: no row-max reduction (timing only)
+        const float mx = fmaxf(st[0][0], m_run);
+#else
         const float mx = xhalf_max(fmaxf(fmaxf(fmaxf(mxa, mxb), fmaxf(mxc, mxd)), m_run));
+#endif
         const float m_new = mx;   // already includes m_run
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
         const float mc = m_use * c2;
@@ -245,7 +251,9 @@ __global__ __launch_bounds__(256, BP_FLASH_MINWAVES) void flash_fwd_dma_kernel(c
 #endif
                 st[kk][r] = x[0];
                 st[kk][r + 1] = x[1];
+#ifndef BP_ABL_NOSUM
                 rs2 += x;
+#endif
             }
         const float rs = rs2[0] + rs2[1];
         l_run = l_run * alpha + rs;
@@ -256,10 +264,12 @@ __global__ __launch_bounds__(256, BP_FLASH_MINWAVES) void flash_fwd_dma_kernel(c
 #else
         if (HAS_V) {
 #endif
+#ifndef BP_ABL_NORESCALE
 #pragma unroll
             for (int n = 0; n < NV; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[n][r] *= alpha;
+#endif
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 if (kk == 1 && skip_hi) continue;

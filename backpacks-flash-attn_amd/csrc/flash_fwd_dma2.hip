@@ -97,6 +97,10 @@ __global__ __launch_bounds__(NWAVE * 64) void flash_fwd_dma2_kernel(const FlashP
             qf[qb][s] = v;
         }
     }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int s = 0; s < KD; ++s) settle(qf[qb][s]);   // see bp_common.h: no vmcnt(0) in the loop
 
     // ---- per-lane DMA source descriptors ------------------------------------------------------------
     int k_row[C::K_DMA], k_col[C::K_DMA];

@@ -14,6 +14,26 @@
 //     `s_barrier` per tile makes every wave's share visible and retires the slot read last step;
 //   * the DMA writes LDS linearly (wave base + lane*16), so the XOR swizzles that make ds_read_b128
 //     (K) and ds_read_b64_tr_b16 (C) conflict-free are applied to the per-lane SOURCE address.
+// Default loop order: sense outer, 64-key tile inner; blocks dispatched heaviest query tiles first.
+// Alternative kept behind -DBP_MIX_SUPER=1 (+ BP_MIX_ORDER=lockstep): key SUPER-tile (256 keys) outer,
+// sense middle, 64-key tile inner, for KD <= 4.  MEASURED (r01_d, B=64 S=1024 k=16 d=768): it does what
+// it was built for -- HBM traffic 5.7 GB -> 2.1 GB per launch, L2 hit rate 18 % -> 74 % -- and is still
+// SLOWER: 1.82 ms (lockstep groups) / 1.49 ms (heaviest-first) against 1.39 ms for this default.  The
+// LDS-DMA fill itself reaches 130 GB/s per CU out of L2 but only 25 GB/s per CU (6.4 TB/s chip) out of
+// HBM (scripts/probes/dma_rate.hip), the default order needs ~0.9 ms of pure HBM time per launch, and
+// the compute stream alone takes 1.0 ms ("no DMA" ablation) -- yet whole-group dispatch loses more to
+// its tail and to all CUs of an XCD pulling the same lines at once than the saved traffic returns.
+// How the alternative works:
+// key SUPER-tile (256 keys) outer, sense middle, 64-key tile inner.
+// The query tiles of one (batch, column chunk) group then walk C in the same order at the same pace
+// (a step costs the same for every tile; tile t merely stops after super-tile t), so when they are
+// co-resident on one XCD the group pulls each C tile from HBM once and the others hit L2 -- with the
+// old sense-outer order the four tiles swept C at different speeds and re-streamed it 2.5x
+// (rocprof r01_c: 5.98 GB per launch against 1.91 GB algorithmic).  Memory locality improves too: one
+// super-tile is a contiguous 6 MB slab of the (B,S,k,d) buffer.  The price is 4x more sense switches;
+// the per-sense operands of a wave (its 32 query fragments and their log-sum-exp) therefore arrive
+// through a per-wave LDS "mailbox" filled by the same DMA queue one step ahead (the lane that DMAs
+// a fragment is the lane that reads it back), so a switch costs KD+1 ds_reads and no vmcnt drain.
 // Rows past the sequence are fetched from a clamped (valid) row: their probabilities are exactly 0
 // by the causal mask and 0 * finite = 0; LDS is zeroed once so never-written pad slots are 0.
 #include "bp_common.h"
@@ -35,13 +55,26 @@ struct MixDmaCfg {
     static constexpr int C_DMA = CTILE / 1024 / NWAVE;   // 4
     static constexpr int DMA_PER_STAGE = K_DMA + C_DMA;
     static constexpr int K_ROWS_PER_DMA = 1024 / KROW;   // 8 or 4
+#ifndef BP_MIX_SUPER
+#define BP_MIX_SUPER 0   // measured slower on MI355X (see the header comment); kept as an A/B build switch
+#endif
+    static constexpr bool SUPER = BP_MIX_SUPER && KD <= 4;   // super-tile loop order + Q mailbox (LDS budget)
+    static constexpr int SUP = BM / BK;                  // key tiles per super-tile
+    static constexpr int QBOX_WAVE = KD * 1024 + 256;    // KD fragments (64 lanes x 16 B) + 64 x lse
+    static constexpr int QBOX_OFF = NSTAGE * STAGE;
+    static constexpr int SMEM = QBOX_OFF + (SUPER ? NWAVE * QBOX_WAVE : 0);
+};
+
+// Position of a pipeline step: super-tile, sense, key tile inside the super-tile.
+struct MixCursor {
+    int st, l, kk;
 };
 
 template <class ET, int KD, bool FULL>
 __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
     using C = MixDmaCfg<KD>;
     using E = Elem<ET>;
-    __shared__ __attribute__((aligned(16))) char smem[C::NSTAGE * C::STAGE];
+    __shared__ __attribute__((aligned(16))) char smem[C::SMEM];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -50,7 +83,31 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
     const int hh = lane >> 5;
 
     int grp, slot;
-    if (p.order == 0) {
+    if (p.order >= 2) {
+        // Per XCD: whole (batch, chunk) groups, heaviest tile first inside a group, the column chunks of
+        // one batch next to each other (same K tiles, adjacent pieces of the same C rows).  The query
+        // tiles of a group then start together and walk C in lockstep -> one HBM read per group, the rest
+        // L2 hits.  In-order dispatch of whole groups leaves a long tail though (the last group's
+        // heaviest tile starts last), so with order 3 only the first 2/3 of an XCD's groups go out this
+        // way and the rest heaviest-tiles-first: same makespan as pure heaviest-first in a list-scheduling
+        // model (8.0 vs the 7.5 ideal for 24 groups on 32 CUs; pure groups: 10.0), ~40 % less C traffic.
+        const int xcd = blockIdx.x & 7;
+        const int s8 = blockIdx.x >> 3;
+        const int gpx = ((p.b + 7) / 8) * p.n_chunks;           // groups per XCD
+        const int nq = p.order == 2 ? gpx : (2 * gpx) / 3;      // dispatched as whole groups
+        int j;
+        if (s8 < nq * p.n_qtiles) {
+            j = s8 / p.n_qtiles;
+            slot = s8 - j * p.n_qtiles;
+        } else {
+            const int r = s8 - nq * p.n_qtiles, rest = gpx - nq;
+            slot = r / rest;
+            j = nq + r - slot * rest;
+        }
+        const int bb = (j / p.n_chunks) * 8 + xcd;
+        if (bb >= p.b) return;
+        grp = bb * p.n_chunks + (j % p.n_chunks);
+    } else if (p.order == 0) {
         if (!xcd_map(blockIdx.x, p.b * p.n_chunks, p.n_qtiles, grp, slot)) return;
     } else {
         // heaviest query tiles of every group first (list scheduling with the longest jobs first),
@@ -75,6 +132,16 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
     const int k_end = min(S, qt * C::BM + C::BM);
     const int nkb = (k_end + C::BK - 1) / C::BK;
     const int nsteps = p.nsenses * nkb;
+    // steps are ordered (super-tile, sense, tile); without SUPER there is one super-tile of nkb tiles
+    const int sup = C::SUPER ? C::SUP : nkb;
+    const int n_super = (nkb + sup - 1) / sup;
+    const int nkb_last = nkb - sup * (n_super - 1);
+    auto advance = [&](MixCursor &c) {
+        if (++c.kk == (c.st + 1 < n_super ? sup : nkb_last)) {
+            c.kk = 0;
+            if (++c.l == p.nsenses) { c.l = 0; ++c.st; }
+        }
+    };
 
     const int q0 = qt * C::BM + wave * 32;
     const int my_q = q0 + l31;
@@ -87,7 +154,7 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
     // ---- zero the ring once: pad slots that no DMA ever writes must read as 0 -----------------------
     {
         const u32x4 z = {0u, 0u, 0u, 0u};
-        for (int off = tid * 16; off < C::NSTAGE * C::STAGE; off += C::NT * 16) lds_write_16B(smem, off, z);
+        for (int off = tid * 16; off < C::SMEM; off += C::NT * 16) lds_write_16B(smem, off, z);
     }
     __syncthreads();
 
@@ -117,24 +184,39 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
     }
 
     const uint32_t lds0 = lds_base_addr(smem);
-    auto issue = [&](int step) {
-        const int l = step / nkb;
-        const int kb = step - l * nkb;
+    // DMA piece `j` (0 .. DMA_PER_STAGE-1: the K pieces, then the C pieces) of pipeline step `step`
+    auto issue_piece = [&](int step, const MixCursor &c, int j) {
+        const int l = c.l;
+        const int kb = c.st * sup + c.kk;
         const uint32_t stage_off = lds0 + (step % C::NSTAGE) * C::STAGE;
-        const uint16_t *kl = kg + (int64_t)l * p.qk_ss;
-        const uint16_t *cl = cg + (int64_t)l * p.c_ss;
-#pragma unroll
-        for (int j = 0; j < C::K_DMA; ++j) {
+        if (j < C::K_DMA) {
             const int key = min(kb * C::BK + k_row[j], S - 1);
-            const uint16_t *src = kl + (int64_t)key * p.qk_rs + k_col[j];
-            if (k_on[j]) dma16(src, stage_off + (wave * C::K_DMA + j) * 1024);
+            const uint16_t *src = kg + (int64_t)l * p.qk_ss + (int64_t)key * p.qk_rs + k_col[j];
+            if (k_on[j]) dma16_d(src, stage_off + (wave * C::K_DMA + j) * 1024);
+        } else {
+            const int jc = j - C::K_DMA;
+            const int key = min(kb * C::BK + c_row[jc], S - 1);
+            const uint16_t *src = cg + (int64_t)l * p.c_ss + (int64_t)key * p.c_rs + c_col[jc];
+            if (c_on[jc]) dma16_d(src, stage_off + C::KTILE + (wave * C::C_DMA + jc) * 1024);
         }
+    };
+    auto issue = [&](int step, const MixCursor &c) {
 #pragma unroll
-        for (int j = 0; j < C::C_DMA; ++j) {
-            const int key = min(kb * C::BK + c_row[j], S - 1);
-            const uint16_t *src = cl + (int64_t)key * p.c_rs + c_col[j];
-            if (c_on[j]) dma16(src, stage_off + C::KTILE + (wave * C::C_DMA + j) * 1024);
+        for (int j = 0; j < C::DMA_PER_STAGE; ++j) issue_piece(step, c, j);
+    };
+    // Inside the main loop the pieces of tile step+2 are NOT issued in one burst after the barrier
+    // (eight waves x five 1-KiB requests at once back up the CU's vector-memory issue path, and every
+    // wave sits in that queue: ablation r01_d, "no DMA" = -33 % time) but in SLOTS spread over the step,
+    // each one behind a group of MFMAs that keeps the matrix pipe busy while the request issues.
+    constexpr int N_SLOTS = 5;
+    auto issue_slot = [&](int step, const MixCursor &c, int slot) {
+#if !defined(BP_ABL_MIX_NOSYNC) && !defined(BP_ABL_MIX_NODMA)
+        if (step < nsteps) {
+#pragma unroll
+            for (int j = 0; j < C::DMA_PER_STAGE; ++j)
+                if (j * N_SLOTS / C::DMA_PER_STAGE == slot) issue_piece(step, c, j);
         }
+#endif
     };
 
     f32x16 acc[C::NB];
@@ -158,19 +240,23 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
     u32x4 qf[KD];
     float lse2 = 0.f;
 
-    // ---- prologue: two tiles in flight ----------------------------------------------------------------
-    issue(0);
-    if (nsteps > 1) issue(1);
-
-    for (int step = 0; step < nsteps; ++step) {
-        const int l = step / nkb;
-        const int kb = step - l * nkb;
-        // my share of tile `step` has landed (the tile after it may still be in flight) ...
-        if (step + 1 < nsteps) wait_vmcnt<C::DMA_PER_STAGE>(); else wait_vmcnt<0>();
-        // ... and so has everybody else's; all waves are also done reading tile step-1
-        __builtin_amdgcn_s_barrier();
-        if (kb == 0 && wave_has_rows) {
-            // new sense: my query's fragments (B operand of S^T = K Q^T) and its log-sum-exp
+    // per-sense operands of this wave: my query's fragments (B operand of S^T = K Q^T) and its LSE
+    const int qbox = C::QBOX_OFF + wave * C::QBOX_WAVE;
+    auto issue_q = [&](int l) {   // SUPER: into the mailbox, through the DMA queue
+        const uint16_t *row = qg + (int64_t)my_q_clamped * p.qk_rs + (int64_t)l * p.qk_ss;
+#pragma unroll
+        for (int s = 0; s < KD; ++s) {
+            const int col = 16 * s + 8 * hh;
+            if (col < p.dk) dma16_d(row + col, lds0 + qbox + s * 1024);
+        }
+        dma4(p.lse + ((int64_t)batch * p.nsenses + l) * p.lse_stride + my_q_clamped, lds0 + qbox + KD * 1024);
+    };
+    auto take_q = [&](int l) {
+        if constexpr (C::SUPER) {
+#pragma unroll
+            for (int s = 0; s < KD; ++s) qf[s] = lds_read_16B(smem, qbox + s * 1024 + lane * 16);
+            lse2 = *reinterpret_cast<const float *>(smem + qbox + KD * 1024 + lane * 4) * kLog2e;
+        } else {
             const uint16_t *row = qg + (int64_t)my_q_clamped * p.qk_rs + (int64_t)l * p.qk_ss;
 #pragma unroll
             for (int s = 0; s < KD; ++s) {
@@ -181,28 +267,88 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
             }
             lse2 = p.lse[((int64_t)batch * p.nsenses + l) * p.lse_stride + my_q_clamped] * kLog2e;
         }
-        if (step + 2 < nsteps) issue(step + 2);   // refill the slot that was read during step-1
+    };
 
-        if (wave_has_rows) {
+    // ---- prologue: mailbox of step 0, then two tiles in flight ---------------------------------------
+    MixCursor cur = {0, 0, 0}, cur1 = cur, cur2;
+    if (C::SUPER && wave_has_rows) issue_q(0);
+    issue(0, cur);
+    advance(cur1);
+    cur2 = cur1;
+    if (nsteps > 1) issue(1, cur1);
+    advance(cur2);
+
+    for (int step = 0; step < nsteps; ++step) {
+        const int l = cur.l;
+        const int kb = cur.st * sup + cur.kk;
+        // my share of tile `step` (and my mailbox, which is older than tile step+1 in the queue) has
+        // landed; the tile after it may still be in flight ...
+#if !defined(BP_ABL_MIX_NOSYNC) && !defined(BP_ABL_MIX_NODMA)   // ablation builds: timing only, wrong results
+        if (step + 1 < nsteps) wait_vmcnt<C::DMA_PER_STAGE>(); else wait_vmcnt<0>();
+#endif
+#if !defined(BP_ABL_MIX_NOSYNC) && !defined(BP_ABL_MIX_NOBARRIER)
+        // ... and so has everybody else's; all waves are also done reading tile step-1
+        __builtin_amdgcn_s_barrier();
+#endif
+        if (cur.kk == 0 && wave_has_rows) take_q(l);
+        if (C::SUPER && step + 1 < nsteps && cur1.kk == 0 && wave_has_rows) {
+            // next step starts a new (super-tile, sense): refill the mailbox.  Queued BEFORE tile step+2, so
+            // the counted wait at the top of the next step covers it.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of the old contents are done
+            issue_q(cur1.l);
+        }
+        // tile step+2 refills the slot that was read during step-1: pieces go out in slots 0..4 below
+#ifdef BP_MIX_BURST
+        for (int sl = 0; sl < N_SLOTS; ++sl) issue_slot(step + 2, cur2, sl);
+#else
+        issue_slot(step + 2, cur2, 0);
+#endif
+
+        {
             const int stage_off = (step % C::NSTAGE) * C::STAGE;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int sub = kb * 2 + kk;
-                if (sub <= my_diag_sub) {
+                const bool live = wave_has_rows && sub <= my_diag_sub;
+                const int coff = stage_off + C::KTILE + kk * 32 * C::CROW;
+                u32x4 pf[2];
+                auto pv = [&](int ks) {
+                    const int rows = coff + ks * 16 * C::CROW;
+#pragma unroll
+                    for (int n = 0; n < C::NB; ++n) {
+                        if (FULL || n < nb_live) {
+#ifdef BP_ABL_MIX_NOCREAD
+                            u32x4 a = qf[n % KD];
+                            asm volatile("" : "+v"(a));
+#else
+                            const u32x2 lo = lds_read_tr16_8B(smem, c_read_off[n] + rows);
+                            const u32x2 hi = lds_read_tr16_8B(smem, c_read_off[n] + rows + 8 * C::CROW);
+                            const u32x4 a = {lo[0], lo[1], hi[0], hi[1]};
+#endif
+                            acc[n] = E::mfma(a, pf[ks], acc[n]);
+                        }
+                    }
+                };
+                if (live) {
                     // one 32-key sub-block: S^T (KD MFMAs) -> P^T -> O^T += C^T P^T (2*NB MFMAs)
                     const int koff = stage_off + kk * 32 * C::KROW;
-                    const int coff = stage_off + C::KTILE + kk * 32 * C::CROW;
                     f32x16 st;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#ifndef BP_ABL_MIX_NOS
 #pragma unroll
                     for (int s = 0; s < KD; ++s) {
                         const u32x4 a = lds_read_16B(smem, k_read_off[s] + koff);
                         st = E::mfma(a, qf[s], st);
                     }
+#ifndef BP_ABL_MIX_NOEXP
 #pragma unroll
                     for (int r = 0; r < 16; ++r) st[r] = fast_exp2(fmaf(st[r], c2, -lse2));
-                    u32x4 pf[2];
+#endif
+#else
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st[r] = lse2;
+#endif
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -223,22 +369,18 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
                                 pf[ks][i] &= keep;
                             }
                     }
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        const int rows = coff + ks * 16 * C::CROW;
-#pragma unroll
-                        for (int n = 0; n < C::NB; ++n) {
-                            if (FULL || n < nb_live) {
-                                const u32x2 lo = lds_read_tr16_8B(smem, c_read_off[n] + rows);
-                                const u32x2 hi = lds_read_tr16_8B(smem, c_read_off[n] + rows + 8 * C::CROW);
-                                const u32x4 a = {lo[0], lo[1], hi[0], hi[1]};
-                                acc[n] = E::mfma(a, pf[ks], acc[n]);
-                            }
-                        }
-                    }
+                    pv(0);
                 }
+#ifndef BP_MIX_BURST
+                issue_slot(step + 2, cur2, 2 * kk + 1);
+#endif
+                if (live) pv(1);
+#ifndef BP_MIX_BURST
+                issue_slot(step + 2, cur2, 2 * kk + 2);
+#endif
             }
         }
+        advance(cur); advance(cur1); advance(cur2);
     }
 
     if (!wave_has_rows || my_q >= S) return;
@@ -258,7 +400,8 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
 
 template <class ET, int KD>
 static hipError_t launch_kd(const MixParams &p, hipStream_t stream) {
-    const int grid = xcd_grid(p.b * p.n_chunks, p.n_qtiles);
+    const int grid = p.order >= 2 ? ((p.b + 7) / 8) * 8 * p.n_chunks * p.n_qtiles
+                                  : xcd_grid(p.b * p.n_chunks, p.n_qtiles);
     dim3 g(grid), t(512);
     if (p.dout % 256 == 0) hipLaunchKernelGGL((sense_mix_dma_kernel<ET, KD, true>), g, t, 0, stream, p);
     else hipLaunchKernelGGL((sense_mix_dma_kernel<ET, KD, false>), g, t, 0, stream, p);

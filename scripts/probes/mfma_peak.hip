@@ -1,0 +1,56 @@
+// Sustained MFMA rate of the whole chip (clock under load included): every wave runs a register-only
+// stream of v_mfma_f32_32x32x16_bf16, optionally with plain VALU / exp instructions in between.
+// build: hipcc --offload-arch=gfx950 -O2 scripts/probes/mfma_peak.hip -o scripts/probes/mfma_peak.bin
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+#define MF(a) "v_mfma_f32_32x32x16_bf16 v[" a "], v[64:67], v[68:71], v[" a "]\n"
+#define EXP4 "v_exp_f32 v80, v88\n v_exp_f32 v81, v89\n v_exp_f32 v82, v90\n v_exp_f32 v83, v91\n"
+#define FMA4 "v_fma_f32 v84, v88, v90, v84\n v_fma_f32 v85, v88, v90, v85\n v_fma_f32 v86, v88, v90, v86\n v_fma_f32 v87, v88, v90, v87\n"
+#define CLOB "v0","v1","v2","v3","v4","v5","v6","v7","v8","v9","v10","v11","v12","v13","v14","v15", \
+ "v16","v17","v18","v19","v20","v21","v22","v23","v24","v25","v26","v27","v28","v29","v30","v31", \
+ "v32","v33","v34","v35","v36","v37","v38","v39","v40","v41","v42","v43","v44","v45","v46","v47", \
+ "v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","v60","v61","v62","v63", \
+ "v64","v65","v66","v67","v68","v69","v70","v71","v80","v81","v82","v83","v84","v85","v86","v87","v88","v89","v90","v91"
+
+template <int MODE>
+__global__ __launch_bounds__(256) void spin(int iters, float *out) {
+    asm volatile("v_mov_b32 v64, 0x3f803f80\n v_mov_b32 v65, 0x3f803f80\n v_mov_b32 v66, 0x3f803f80\n v_mov_b32 v67, 0x3f803f80\n"
+                 "v_mov_b32 v68, 0x3c003c00\n v_mov_b32 v69, 0x3c003c00\n v_mov_b32 v70, 0x3c003c00\n v_mov_b32 v71, 0x3c003c00\n"
+                 "v_mov_b32 v88, 0xbf800000\n v_mov_b32 v89, 0xbf800000\n v_mov_b32 v90, 0x3f000000\n v_mov_b32 v91, 0x3f000000\n" ::: CLOB);
+    for (int i = 0; i < iters; ++i) {
+        if (MODE == 0) asm volatile(".rept 4\n" MF("0:15") MF("16:31") MF("32:47") MF("48:63") ".endr\n" ::: CLOB);
+        if (MODE == 1) asm volatile(".rept 4\n" MF("0:15") EXP4 MF("16:31") FMA4 MF("32:47") EXP4 MF("48:63") FMA4 ".endr\n" ::: CLOB);
+        if (MODE == 2) asm volatile(".rept 4\n" MF("0:15") EXP4 FMA4 FMA4 MF("16:31") EXP4 FMA4 FMA4 MF("32:47") EXP4 FMA4 FMA4 MF("48:63") EXP4 FMA4 FMA4 ".endr\n" ::: CLOB);
+    }
+    float r;
+    asm volatile("s_nop 15\n s_nop 15\n v_add_f32 %0, v0, v80" : "=v"(r) :: CLOB);
+    if (r == 12345.f) out[0] = r;
+}
+
+template <int MODE>
+void run(const char *name, int wgs_per_cu) {
+    float *d; hipMalloc(&d, 4);
+    const int iters = 2000, grid = 256 * wgs_per_cu;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hipLaunchKernelGGL(spin<MODE>, dim3(grid), dim3(256), 0, 0, 10, d);
+    hipDeviceSynchronize();
+    hipEventRecord(a);
+    hipLaunchKernelGGL(spin<MODE>, dim3(grid), dim3(256), 0, 0, iters, d);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    const double mfma = (double)grid * 4 * iters * 16;
+    const double tf = mfma * 32768.0 / ms / 1e9;
+    printf("%-44s %d waves/SIMD: %8.3f ms  %8.1f TFLOP/s  -> %5.2f GHz-equivalent at 32 cyc/MFMA\n", name, wgs_per_cu, ms, tf,
+           mfma / (1024.0 * wgs_per_cu) * wgs_per_cu * 32 / ms / 1e6);
+    hipFree(d);
+}
+
+int main() {
+    for (int w : {1, 2, 3}) {
+        run<0>("mfma only", w);
+        run<1>("mfma + 2 exp + 2 fma per mfma", w);
+        run<2>("mfma + 4 exp + 8 fma per mfma", w);
+    }
+    return 0;
+}
