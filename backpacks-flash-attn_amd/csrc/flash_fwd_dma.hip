@@ -15,6 +15,9 @@
 #ifndef BP_FLASH_STAGES
 #define BP_FLASH_STAGES 2
 #endif
+#ifndef BP_FLASH_DEFER
+#define BP_FLASH_DEFER 8.f   // deferred-rescale threshold in exp2 units; negative = always rescale
+#endif
 #ifndef BP_FLASH_MINWAVES
 #define BP_FLASH_MINWAVES 1
 #endif
@@ -227,14 +230,20 @@ __global__ __launch_bounds__(256, BP_FLASH_MINWAVES) void flash_fwd_dma_kernel(c
             mxd = fmaxf(mxd, st[1][8 + r]);
         }
 #ifdef BP_ABL_NOMAX   // ablation: no row-max reduction (timing only)
-        const float mx = fmaxf(st[0][0], m_run);
+        const float mt = st[0][0];
 #else
-        const float mx = xhalf_max(fmaxf(fmaxf(fmaxf(mxa, mxb), fmaxf(mxc, mxd)), m_run));
+        const float mt = xhalf_max(fmaxf(fmaxf(mxa, mxb), fmaxf(mxc, mxd)));   // max of this tile's scores
 #endif
-        const float m_new = mx;   // already includes m_run
+        // Deferred rescale: while no row's maximum grows by more than BP_FLASH_DEFER (in exp2 units) the
+        // old reference maximum is kept -- P <= 2^BP_FLASH_DEFER, harmless in fp32 / bf16 / fp16 -- and
+        // the O / l rescale (32 multiplies + an exp2 per tile) is skipped for the whole wave.  A fresh row
+        // (m_run = -inf) or a fully masked tile row (NaN difference) fails the test and takes the exact path.
+        const bool defer = HAS_V && BP_FLASH_DEFER >= 0.f && __all((mt - m_run) * c2 <= BP_FLASH_DEFER);
+        const float m_new = defer ? m_run : fmaxf(mt, m_run);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
         const float mc = m_use * c2;
-        const float alpha = fast_exp2(m_run * c2 - mc);
+        float alpha = 1.f;
+        if (!defer) alpha = fast_exp2(m_run * c2 - mc);
         m_run = m_new;
         // p = exp2(s*c2 - mc): packed fma on register pairs, packed row-sum accumulation
         const f32x2 c2v = {c2, c2}, mcv = {-mc, -mc};
@@ -256,7 +265,7 @@ __global__ __launch_bounds__(256, BP_FLASH_MINWAVES) void flash_fwd_dma_kernel(c
 #endif
             }
         const float rs = rs2[0] + rs2[1];
-        l_run = l_run * alpha + rs;
+        l_run = defer ? l_run + rs : l_run * alpha + rs;
         BP_STAMP(2)
 #ifdef BP_ABL_NOPV
         asm volatile("" ::"v"(st[0][0]), "v"(st[0][15]), "v"(st[1][0]), "v"(st[1][15]), "v"(alpha));
@@ -265,10 +274,12 @@ __global__ __launch_bounds__(256, BP_FLASH_MINWAVES) void flash_fwd_dma_kernel(c
         if (HAS_V) {
 #endif
 #ifndef BP_ABL_NORESCALE
+            if (!defer) {
 #pragma unroll
-            for (int n = 0; n < NV; ++n)
+                for (int n = 0; n < NV; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[n][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) acc[n][r] *= alpha;
+            }
 #endif
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
