@@ -24,7 +24,7 @@ SIGNATURES = {
     'bp_strerror': (ctypes.c_char_p, [_i32]),
     'bp_abi_version': (_i32, []),
     'bp_flash_fwd': (_i32, [_ptr] * 7 + [_i32] * 5 + [_i64] * 9 + [_f32, _i32, _i32, _ptr]),
-    'bp_flash_bwd': (_i32, [_ptr] * 11 + [_i32] * 5 + [_i64] * 15 + [_f32, _i32, _i32, _ptr]),
+    'bp_flash_bwd': (_i32, [_ptr] * 12 + [_i32] * 5 + [_i64] * 17 + [_f32, _i32, _i32, _ptr]),
     'bp_attn_probs': (_i32, [_ptr] * 4 + [_i32] * 5 + [_i64] * 10 + [_f32, _i32, _i32, _ptr]),
     'bp_sense_lse': (_i32, [_ptr] * 2 + [_i32] * 4 + [_i64] * 4 + [_f32, _i32, _ptr]),
     'bp_sense_alpha': (_i32, [_ptr] * 3 + [_i32] * 5 + [_i64] * 4 + [_f32, _i32, _ptr]),
@@ -150,27 +150,21 @@ def flash_bwd(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seql
     else:
         batch = total_q // max_seqlen_q
     lse_len = softmax_lse.shape[-1]
-    # D_i = sum_d dO_i[d] * O_i[d], laid out like the LSE: (batch, nheads, lse_len)
-    rowdot = (dout.float() * out.float()).sum(-1)                       # (total_q, nheads)
-    dsum = torch.zeros((batch, nheads, lse_len), dtype=torch.float32, device=q.device)
-    if cu_seqlens_q is None or total_q == batch * max_seqlen_q:
-        dsum[:, :, :max_seqlen_q] = rowdot.view(batch, max_seqlen_q, nheads).transpose(1, 2)
-    else:
-        bounds = cu_seqlens_q.tolist()
-        for b in range(batch):
-            n = bounds[b + 1] - bounds[b]
-            dsum[b, :, :n] = rowdot[bounds[b]:bounds[b + 1]].t()
+    if out.stride(-1) != 1:
+        out = out.contiguous()
+    # workspace for D_i = sum_d dO_i[d] * O_i[d] (filled by the dQ kernel, read by the dK/dV kernel)
+    dsum = torch.empty((batch, nheads, lse_len), dtype=torch.float32, device=q.device)
     with torch.cuda.device(q.device):
         code = lib().bp_flash_bwd(
-            dout.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), softmax_lse.data_ptr(),
-            dsum.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+            dout.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
+            softmax_lse.data_ptr(), dsum.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
             cu_seqlens_q.data_ptr() if cu_seqlens_q is not None else None,
             cu_seqlens_k.data_ptr() if cu_seqlens_k is not None else None,
             batch, nheads, d, int(max_seqlen_q), int(max_seqlen_k),
             dout.stride(0), dout.stride(1), q.stride(0), q.stride(1), k.stride(0), k.stride(1),
-            v.stride(0), v.stride(1), dq.stride(0), dq.stride(1), dk.stride(0), dk.stride(1),
-            dv.stride(0), dv.stride(1), lse_len, float(softmax_scale), int(bool(causal)),
-            _dtype_code(q), _stream())
+            v.stride(0), v.stride(1), out.stride(0), out.stride(1), dq.stride(0), dq.stride(1),
+            dk.stride(0), dk.stride(1), dv.stride(0), dv.stride(1), lse_len, float(softmax_scale),
+            int(bool(causal)), _dtype_code(q), _stream())
     _check(code, 'bp_flash_bwd')
     return dq, dk, dv
 

@@ -242,14 +242,15 @@ int bp_sense_mix(const void *qk, const void *content, void *out, float *lse_ws, 
     return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
 }
 
-int bp_flash_bwd(const void *dout, const void *q, const void *k, const void *v,
-                 const float *softmax_lse, const float *dsum, void *dq, void *dk, void *dv,
+int bp_flash_bwd(const void *dout, const void *q, const void *k, const void *v, const void *out,
+                 const float *softmax_lse, float *dsum_ws, void *dq, void *dk, void *dv,
                  const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k,
                  int batch, int nheads, int head_dim, int max_seqlen_q, int max_seqlen_k,
                  int64_t do_row_stride, int64_t do_head_stride,
                  int64_t q_row_stride, int64_t q_head_stride,
                  int64_t k_row_stride, int64_t k_head_stride,
                  int64_t v_row_stride, int64_t v_head_stride,
+                 int64_t o_row_stride, int64_t o_head_stride,
                  int64_t dq_row_stride, int64_t dq_head_stride,
                  int64_t dk_row_stride, int64_t dk_head_stride,
                  int64_t dv_row_stride, int64_t dv_head_stride,
@@ -258,22 +259,23 @@ int bp_flash_bwd(const void *dout, const void *q, const void *k, const void *v,
     if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
     if (head_dim < 8 || head_dim > 64 || head_dim % 8 != 0) return BP_ERR_HEAD_DIM;
     if (batch <= 0 || nheads <= 0 || max_seqlen_q <= 0 || max_seqlen_k <= 0) return BP_ERR_SHAPE;
-    if (!dout || !q || !k || !v || !softmax_lse || !dsum || !dq || !dk || !dv) return BP_ERR_SHAPE;
+    if (!dout || !q || !k || !v || !out || !softmax_lse || !dsum_ws || !dq || !dk || !dv) return BP_ERR_SHAPE;
     if ((cu_seqlens_q == nullptr) != (cu_seqlens_k == nullptr)) return BP_ERR_SHAPE;
     if (!scale_ok(softmax_scale)) return BP_ERR_SCALE;
-    const void *ptrs[] = {dout, q, k, v, dq, dk, dv, softmax_lse, dsum};
+    const void *ptrs[] = {dout, q, k, v, out, dq, dk, dv, softmax_lse, dsum_ws};
     for (const void *ptr : ptrs) if (!aligned16(ptr)) return BP_ERR_SHAPE;
     const int64_t strides[] = {do_row_stride, do_head_stride, q_row_stride, q_head_stride, k_row_stride,
-                               k_head_stride, v_row_stride, v_head_stride, dq_row_stride, dq_head_stride,
+                               k_head_stride, v_row_stride, v_head_stride, o_row_stride, o_head_stride, dq_row_stride, dq_head_stride,
                                dk_row_stride, dk_head_stride, dv_row_stride, dv_head_stride};
     for (int64_t st : strides) if (!mult8(st)) return BP_ERR_SHAPE;
     if (lse_stride % 16 != 0) return BP_ERR_SHAPE;
 
     bp::FlashBwdParams p{};
-    p.q = q; p.k = k; p.v = v; p.dout = dout; p.lse = softmax_lse; p.dsum = dsum;
+    p.q = q; p.k = k; p.v = v; p.dout = dout; p.out = out; p.lse = softmax_lse; p.dsum = dsum_ws;
     p.dq = dq; p.dk = dk; p.dv = dv; p.cu_q = cu_seqlens_q; p.cu_k = cu_seqlens_k;
     p.q_rs = q_row_stride; p.q_hs = q_head_stride; p.k_rs = k_row_stride; p.k_hs = k_head_stride;
     p.v_rs = v_row_stride; p.v_hs = v_head_stride; p.do_rs = do_row_stride; p.do_hs = do_head_stride;
+    p.o_rs = o_row_stride; p.o_hs = o_head_stride;
     p.dq_rs = dq_row_stride; p.dq_hs = dq_head_stride; p.dk_rs = dk_row_stride; p.dk_hs = dk_head_stride;
     p.dv_rs = dv_row_stride; p.dv_hs = dv_head_stride;
     p.lse_stride = lse_stride;

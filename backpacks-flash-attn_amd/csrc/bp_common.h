@@ -53,6 +53,8 @@ template <> struct Elem<BF16> {
     static BP_DEV uint16_t from_float(float x) {
         return __builtin_bit_cast(uint16_t, (__bf16)x);
     }
+    static BP_DEV float lo_f32(uint32_t w) { return as_f32(w << 16); }
+    static BP_DEV float hi_f32(uint32_t w) { return as_f32(w & 0xffff0000u); }
 };
 
 template <> struct Elem<F16> {
@@ -67,6 +69,8 @@ template <> struct Elem<F16> {
     static BP_DEV uint16_t from_float(float x) {
         return __builtin_bit_cast(uint16_t, (_Float16)x);
     }
+    static BP_DEV float lo_f32(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu)); }
+    static BP_DEV float hi_f32(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
 };
 
 // 8 consecutive 16-bit elements as one 16-byte global load (pointer must be 16-B aligned).

@@ -24,12 +24,12 @@ struct FlashParams {
 };
 
 struct FlashBwdParams {
-    const void *q, *k, *v, *dout;
+    const void *q, *k, *v, *dout, *out;
     const float *lse;         // (b, h, lse_stride) from the forward
-    const float *dsum;        // (b, h, lse_stride): D_i = sum_d dO_i[d] * O_i[d]
+    float *dsum;              // (b, h, lse_stride) workspace: D_i = sum_d dO_i[d] * O_i[d], written by the dQ kernel
     void *dq, *dk, *dv;
     const int *cu_q, *cu_k;   // NULL: fixed length
-    int64_t q_rs, q_hs, k_rs, k_hs, v_rs, v_hs, do_rs, do_hs;
+    int64_t q_rs, q_hs, k_rs, k_hs, v_rs, v_hs, do_rs, do_hs, o_rs, o_hs;
     int64_t dq_rs, dq_hs, dk_rs, dk_hs, dv_rs, dv_hs;
     int64_t lse_stride;
     int b, h, d, max_sq, max_sk, causal;

@@ -1,6 +1,6 @@
 // Attention backward for gfx950 (SURVEY.md section 8(f) "next" row 1): dQ, dK, dV of
 //     O = softmax(scale * Q K^T [+causal]) V
-// from Q, K, V, dO, the forward's row log-sum-exp L and D_i = sum_d dO_i[d] * O_i[d].
+// from Q, K, V, dO, O and the forward's row log-sum-exp L (D_i = sum_d dO_i[d] * O_i[d] is formed here).
 // Takes the place of the reference's fmha_bwd_dq_dk_dv_loop_kernel
 // (csrc/flash_attn/src/fmha_bwd_launch_template.h:31-114, src/fmha_dgrad_kernel_1xN_loop.h:95-711;
 // Python side flash_attn/flash_attn_interface.py:31-47,70-84).  P is recomputed from L, as upstream.
@@ -15,8 +15,10 @@
 //     tiles that can see those keys.  S = Q K^T and dP = dO V^T come out with lane = key and the
 //     queries along the registers, which is exactly the B-operand layout of the two products that
 //     contract over queries (dV^T = dO^T P, dK^T = Q^T dS); their A operands are transposing LDS reads.
-//   * dq: a wave owns 32 QUERIES (Q, dO, L, D in registers); it sweeps key tiles as the forward does:
-//     S^T = K Q^T, dP^T = V dO^T, dS^T feeds dQ^T = K^T dS^T.
+//   * dq (runs FIRST): a wave owns 32 QUERIES (Q, dO, L, D in registers); it sweeps key tiles as the forward
+//     does: S^T = K Q^T, dP^T = V dO^T, dS^T feeds dQ^T = K^T dS^T.  Its prologue forms D for its rows from
+//     the dO and O fragments it holds anyway and publishes it for the dkdv kernel (which follows on the same
+//     stream), so no separate reduction pass over dO and O is needed.
 // A tile that is read both row-wise (ds_read_b128) and transposed (ds_read_b64_tr_b16) is kept as two
 // LDS images, each with the swizzle its read pattern needs; tiles arrive by the LDS-DMA ring (bp_dma.h).
 #include "bp_common.h"
@@ -334,20 +336,30 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashBwdParams 
     float lse2 = 0.f, dsum = 0.f;
     {
         const int q = min(my_q, seq_q - 1);
+        const uint16_t *og = reinterpret_cast<const uint16_t *>(p.out) + (q_row0 + q) * p.o_rs + (int64_t)head * p.o_hs;
+        float part = 0.f;   // my 8*KD columns of dO . O
 #pragma unroll
         for (int s = 0; s < KD; ++s) {
             const int col = 16 * s + 8 * hh;
-            u32x4 a = {0u, 0u, 0u, 0u}, b = {0u, 0u, 0u, 0u};
+            u32x4 a = {0u, 0u, 0u, 0u}, b = {0u, 0u, 0u, 0u}, o = {0u, 0u, 0u, 0u};
             if (col < p.d) {
                 a = ld_global_16B(qg + (int64_t)q * p.q_rs + col);
                 b = ld_global_16B(dog + (int64_t)q * p.do_rs + col);
+                o = ld_global_16B(og + col);
             }
             qf[s] = a;
             dof[s] = b;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t bw = b[i], ow = o[i];   // by-value copies (bp_common.h, as_f32)
+                part = fmaf(E::lo_f32(bw), E::lo_f32(ow), part);
+                part = fmaf(E::hi_f32(bw), E::hi_f32(ow), part);
+            }
         }
         const int64_t so = ((int64_t)batch * p.h + head) * p.lse_stride + q;
         lse2 = p.lse[so] * kLog2e;
-        dsum = p.dsum[so];
+        dsum = xhalf_sum(part);   // the two half-waves hold the two 8-column halves of every 16
+        if (hh == 0 && wave_has_rows && my_q < seq_q) p.dsum[so] = dsum;
 #pragma unroll
         for (int s = 0; s < KD; ++s) { settle(qf[s]); settle(dof[s]); }
         settle(lse2); settle(dsum);
@@ -464,12 +476,13 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashBwdParams 
 
 template <class ET, int KD, int NV>
 static hipError_t launch_one(const FlashBwdParams &p, hipStream_t stream) {
-    const int gk = xcd_grid(p.b * p.h, (p.max_sk + 127) / 128);
-    hipLaunchKernelGGL((flash_bwd_dkdv_kernel<ET, KD, NV>), dim3(gk), dim3(256), 0, stream, p);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    // dq first: it also produces the D vector the dkdv kernel consumes
     const int gq = xcd_grid(p.b * p.h, (p.max_sq + 127) / 128);
     hipLaunchKernelGGL((flash_bwd_dq_kernel<ET, KD, NV>), dim3(gq), dim3(256), 0, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int gk = xcd_grid(p.b * p.h, (p.max_sk + 127) / 128);
+    hipLaunchKernelGGL((flash_bwd_dkdv_kernel<ET, KD, NV>), dim3(gk), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -134,25 +134,27 @@ int bp_sense_mix(const void *qk, const void *content, void *out, float *lse_ws, 
                  float softmax_scale, int dtype, bp_stream_t stream);
 
 /*
- * bp_flash_bwd -- attention backward: dq, dk, dv from q, k, v, dout, the forward's softmax_lse and
- *   dsum[b,h,i] = sum_d dout_i[d] * out_i[d].
+ * bp_flash_bwd -- attention backward: dq, dk, dv from q, k, v, dout and the forward's out and softmax_lse.
  * Replaces flash_attn_cuda.bwd / mha_bwd (csrc/flash_attn/fmha_api.cpp:337-504) called by
  * _flash_attn_backward (flash_attn/flash_attn_interface.py:31-47), no-dropout path.  P is recomputed
  * from the LSE as upstream; the result is deterministic (no atomics).
- *   q, dout, dq  (total_q, nheads, head_dim); k, v, dk, dv (total_k, nheads, head_dim): 16-bit, last
+ *   q, dout, out, dq  (total_q, nheads, head_dim); k, v, dk, dv (total_k, nheads, head_dim): 16-bit, last
  *                stride 1, 16-byte aligned rows, head_dim % 8 == 0 and <= 64
- *   softmax_lse, dsum  (batch, nheads, lse_stride) fp32
+ *   softmax_lse  (batch, nheads, lse_stride) fp32
+ *   dsum_ws      (batch, nheads, lse_stride) fp32 workspace, contents undefined on entry: the kernels put
+ *                D[b,h,i] = sum_d dout_i[d] * out_i[d] there (upstream's dsoftmax_sum, fmha_api.cpp:421)
  *   cu_seqlens_*       as in bp_flash_fwd (NULL = fixed length)
  * Returns BP_ERR_HEAD_DIM for head dims this kernel does not cover (callers recompute eagerly).
  */
-int bp_flash_bwd(const void *dout, const void *q, const void *k, const void *v,
-                 const float *softmax_lse, const float *dsum, void *dq, void *dk, void *dv,
+int bp_flash_bwd(const void *dout, const void *q, const void *k, const void *v, const void *out,
+                 const float *softmax_lse, float *dsum_ws, void *dq, void *dk, void *dv,
                  const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k,
                  int batch, int nheads, int head_dim, int max_seqlen_q, int max_seqlen_k,
                  int64_t do_row_stride, int64_t do_head_stride,
                  int64_t q_row_stride, int64_t q_head_stride,
                  int64_t k_row_stride, int64_t k_head_stride,
                  int64_t v_row_stride, int64_t v_head_stride,
+                 int64_t o_row_stride, int64_t o_head_stride,
                  int64_t dq_row_stride, int64_t dq_head_stride,
                  int64_t dk_row_stride, int64_t dk_head_stride,
                  int64_t dv_row_stride, int64_t dv_head_stride,

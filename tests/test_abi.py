@@ -68,6 +68,18 @@ def test_argument_validation_returns_before_any_launch():
     assert h.bp_sense_lse(p, p, 1, 0, 4, 16, 1, 1, 1, 1, 0.25, 1, null) == -3
     assert h.bp_attn_probs(p, p, p, p, 1, 1, 64, 16, 0, 1, 1, 1, 1, 1, 1, 16, 1, 1, 1, 0.125, 1, 1,
                            null) == -3
+    # backward: head dim the kernel does not cover, bad dtype, null dq, odd lse stride
+    st = [64] * 16
+    assert h.bp_flash_bwd(p, p, p, p, p, p, p, p, p, p, null, null, 1, 1, 128, 16, 16, *st, 16, 0.125, 1, 1,
+                          null) == -2
+    assert h.bp_flash_bwd(p, p, p, p, p, p, p, p, p, p, null, null, 1, 1, 64, 16, 16, *st, 16, 0.125, 1, 5,
+                          null) == -1
+    assert h.bp_flash_bwd(p, p, p, p, p, p, p, null, p, p, null, null, 1, 1, 64, 16, 16, *st, 16, 0.125, 1, 1,
+                          null) == -3
+    assert h.bp_flash_bwd(p, p, p, p, p, p, p, p, p, p, null, null, 1, 1, 64, 16, 16, *st, 17, 0.125, 1, 1,
+                          null) == -3
+    assert h.bp_flash_bwd(p, p, p, p, p, p, p, p, p, p, null, null, 1, 1, 64, 16, 16, *st, 16, -1.0, 1, 1,
+                          null) == -4
 
 
 def test_python_binding_refuses_cpu_tensors_loudly():
