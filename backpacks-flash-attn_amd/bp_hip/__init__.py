@@ -134,7 +134,7 @@ def flash_fwd(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen
 def flash_bwd_supported(q):
     """Shapes the HIP backward covers (others recompute eagerly in the autograd Functions)."""
     return (q.is_cuda and q.dtype in (torch.float16, torch.bfloat16) and q.shape[-1] % 8 == 0
-            and q.shape[-1] <= 64)
+            and q.shape[-1] <= 128)
 
 
 def flash_bwd(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seqlens_k, max_seqlen_q,

@@ -257,7 +257,7 @@ int bp_flash_bwd(const void *dout, const void *q, const void *k, const void *v, 
                  int64_t lse_stride, float softmax_scale, int is_causal, int dtype,
                  bp_stream_t stream) {
     if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
-    if (head_dim < 8 || head_dim > 64 || head_dim % 8 != 0) return BP_ERR_HEAD_DIM;
+    if (head_dim < 8 || head_dim > 128 || head_dim % 8 != 0) return BP_ERR_HEAD_DIM;
     if (batch <= 0 || nheads <= 0 || max_seqlen_q <= 0 || max_seqlen_k <= 0) return BP_ERR_SHAPE;
     if (!dout || !q || !k || !v || !out || !softmax_lse || !dsum_ws || !dq || !dk || !dv) return BP_ERR_SHAPE;
     if ((cu_seqlens_q == nullptr) != (cu_seqlens_k == nullptr)) return BP_ERR_SHAPE;

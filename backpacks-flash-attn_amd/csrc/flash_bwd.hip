@@ -486,24 +486,24 @@ static hipError_t launch_one(const FlashBwdParams &p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-// head_dim % 8 == 0 and <= 64 (the trunk's 64 and the senses' 48/40/24), 16-byte friendly strides.
+template <class ET>
+static hipError_t launch_et(const FlashBwdParams &p, hipStream_t stream) {
+    switch ((p.d + 15) / 16) {
+        case 1: return launch_one<ET, 1, 1>(p, stream);
+        case 2: return launch_one<ET, 2, 1>(p, stream);
+        case 3: return launch_one<ET, 3, 2>(p, stream);
+        case 4: return launch_one<ET, 4, 2>(p, stream);
+        case 5: return launch_one<ET, 5, 4>(p, stream);   // d_h = 80 (Mini)
+        case 6: return launch_one<ET, 6, 4>(p, stream);
+        case 7: return launch_one<ET, 7, 4>(p, stream);
+        default: return launch_one<ET, 8, 4>(p, stream);
+    }
+}
+
+// head_dim % 8 == 0 and <= 128 (the trunk's 64 / 80 and the senses' 48/40/24), 16-byte friendly strides.
 hipError_t launch_flash_bwd(const FlashBwdParams &p, int dtype, hipStream_t stream) {
-    if (p.d > 64) return hipErrorNotSupported;
-    const int kd = (p.d + 15) / 16;
-    if (dtype == 1) {
-        switch (kd) {
-            case 1: return launch_one<BF16, 1, 1>(p, stream);
-            case 2: return launch_one<BF16, 2, 1>(p, stream);
-            case 3: return launch_one<BF16, 3, 2>(p, stream);
-            default: return launch_one<BF16, 4, 2>(p, stream);
-        }
-    }
-    switch (kd) {
-        case 1: return launch_one<F16, 1, 1>(p, stream);
-        case 2: return launch_one<F16, 2, 1>(p, stream);
-        case 3: return launch_one<F16, 3, 2>(p, stream);
-        default: return launch_one<F16, 4, 2>(p, stream);
-    }
+    if (p.d > 128) return hipErrorNotSupported;
+    return dtype == 1 ? launch_et<BF16>(p, stream) : launch_et<F16>(p, stream);
 }
 
 }  // namespace bp

@@ -3,8 +3,8 @@ flash_attn/flash_attn_interface.py (public functions :242-380), with `flash_attn
 (:23-26) replaced by bp_hip.flash_fwd (C ABI bp_flash_fwd, include/bp_hip.h) and
 `flash_attn_cuda.bwd` (:38-43) by bp_hip.flash_bwd (bp_flash_bwd).
 
-The HIP backward covers head dims <= 64 (the trunk's 64, the senses' 48/40/24); for larger heads
-the autograd Functions fall back to differentiating an eager recomputation.  Dropout inside the
+The HIP backward covers the same head dims as the forward fast path (% 8 == 0, <= 128); for anything
+else the autograd Functions fall back to differentiating an eager recomputation.  Dropout inside the
 kernel is not implemented; `dropout_p` must be 0 as it is in eval / the forward benchmark.
 """
 import torch
@@ -66,7 +66,7 @@ def _eager_varlen(q, k, v, cu_q, cu_k, softmax_scale, causal):
 
 
 class _FlashAttnFuncBase(torch.autograd.Function):
-    """forward = HIP kernel; backward = HIP kernels (head dim <= 64) or autograd through
+    """forward = HIP kernel; backward = HIP kernels (head dim % 8 == 0) or autograd through
     `_eager_varlen` (see module docstring)."""
 
     @staticmethod

@@ -139,12 +139,11 @@ int bp_sense_mix(const void *qk, const void *content, void *out, float *lse_ws, 
  * _flash_attn_backward (flash_attn/flash_attn_interface.py:31-47), no-dropout path.  P is recomputed
  * from the LSE as upstream; the result is deterministic (no atomics).
  *   q, dout, out, dq  (total_q, nheads, head_dim); k, v, dk, dv (total_k, nheads, head_dim): 16-bit, last
- *                stride 1, 16-byte aligned rows, head_dim % 8 == 0 and <= 64
+ *                stride 1, 16-byte aligned rows, head_dim % 8 == 0 and <= 128
  *   softmax_lse  (batch, nheads, lse_stride) fp32
  *   dsum_ws      (batch, nheads, lse_stride) fp32 workspace, contents undefined on entry: the kernels put
  *                D[b,h,i] = sum_d dout_i[d] * out_i[d] there (upstream's dsoftmax_sum, fmha_api.cpp:421)
  *   cu_seqlens_*       as in bp_flash_fwd (NULL = fixed length)
- * Returns BP_ERR_HEAD_DIM for head dims this kernel does not cover (callers recompute eagerly).
  */
 int bp_flash_bwd(const void *dout, const void *q, const void *k, const void *v, const void *out,
                  const float *softmax_lse, float *dsum_ws, void *dq, void *dk, void *dv,

@@ -70,7 +70,7 @@ def test_argument_validation_returns_before_any_launch():
                            null) == -3
     # backward: head dim the kernel does not cover, bad dtype, null dq, odd lse stride
     st = [64] * 16
-    assert h.bp_flash_bwd(p, p, p, p, p, p, p, p, p, p, null, null, 1, 1, 128, 16, 16, *st, 16, 0.125, 1, 1,
+    assert h.bp_flash_bwd(p, p, p, p, p, p, p, p, p, p, null, null, 1, 1, 136, 16, 16, *st, 16, 0.125, 1, 1,
                           null) == -2
     assert h.bp_flash_bwd(p, p, p, p, p, p, p, p, p, p, null, null, 1, 1, 64, 16, 16, *st, 16, 0.125, 1, 5,
                           null) == -1

@@ -68,7 +68,7 @@ def _run_bwd(q, k, v, dout, causal, scale, cu_q=None, cu_k=None, max_q=None, max
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('causal', [True, False])
-@pytest.mark.parametrize('d', [64, 48, 40, 24, 16, 8, 32])
+@pytest.mark.parametrize('d', [64, 48, 40, 24, 16, 8, 32, 80, 128, 96])
 @pytest.mark.parametrize('seqlen', [97, 128, 200, 257, 512])
 def test_flash_bwd_fixed_len(seqlen, d, causal, dtype):
     """Shape sweep after the reference's test_flash_attn_unpadded_qkvpacked (tests/test_flash_attn.py:350-397)."""
@@ -168,7 +168,7 @@ def test_flash_bwd_seq2048_rows():
 
 def test_flash_bwd_rejects_large_head_dim():
     bp = _bp()
-    q = torch.randn(64, 2, 128, device=DEV).bfloat16()
+    q = torch.randn(64, 2, 136, device=DEV).bfloat16()
     assert not bp.flash_bwd_supported(q)
     cu = torch.tensor([0, 64], dtype=torch.int32, device=DEV)
     lse = torch.zeros(1, 2, 64, device=DEV)
@@ -178,10 +178,10 @@ def test_flash_bwd_rejects_large_head_dim():
 
 
 @pytest.mark.parametrize('packing', ['qkv', 'kv', 'none'])
-@pytest.mark.parametrize('d', [64, 128])
+@pytest.mark.parametrize('d', [64, 80, 36])
 def test_autograd_functions_use_backward(packing, d):
-    """loss.backward() through the public functions: d=64 takes the HIP backward, d=128 the eager
-    recomputation; both must match fp32 autograd by the same criterion."""
+    """loss.backward() through the public functions: d=64 / 80 take the HIP backward, d=36 (not a multiple
+    of 8) the eager recomputation; both must match fp32 autograd by the same criterion."""
     from flash_attn import flash_attn_interface as F
     torch.manual_seed(6)
     b, s, h = 2, 160, 2
