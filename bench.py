@@ -180,6 +180,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-threads', type=int, default=None)
     ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--graph', action='store_true',
+                    help='capture one forward in a HIP graph and replay it per step (launch-bound small '
+                         'configs; per-kernel events are not taken in this mode)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -206,12 +209,29 @@ def main():
                         generator=torch.Generator(device=device).manual_seed(1234 + rank))
 
     clock = KernelClock()
-    if not args.no_kernel_events:
+    if not args.no_kernel_events and not args.graph:
         instrument(clock)
 
-    def step():
+    def eager_step():
         with torch.no_grad():
             return model(ids).logits
+
+    step = eager_step
+    if args.graph:
+        # HIP graph: the whole forward (torch ops and the C-ABI launches alike go to the capture stream)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            graph_out = eager_step()
+
+        def step():
+            graph.replay()
+            return graph_out
 
     for _ in range(args.warmup):
         out = step()
@@ -268,6 +288,7 @@ def main():
             'vs_baseline': None,
             'dtype': dtype_name,
             'data': 'synthetic token ids, random weights (reference init scheme)',
+            'launch': 'hip-graph replay' if args.graph else 'eager launches',
             'config': {'workload': f'Backpack-{model_name} forward (ids -> logits), d={cfg.n_embd}, '
                                    f'{cfg.n_head} heads, {cfg.n_layer} layers, k={cfg.num_content_vectors} '
                                    f'senses, vocab {cfg.vocab_size}, seq {seq}',

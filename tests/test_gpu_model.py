@@ -98,6 +98,38 @@ def test_micro_config1_forward(dtype, fused):
         assert err <= 3 * base + 1e-3, (name, err, base)
 
 
+@pytest.mark.parametrize('fused', [False, True])
+def test_mini_k64_config4_forward(fused):
+    """BASELINE config 4 shape family (Backpack-Mini sense ablation: d_h = 80, k = 64 -> d_k = 10,
+    shrink_final_inner), 2 layers, B=2, S=192: exercises the generic-head-dim flash path and the zero-padded
+    d_k = 10 sense kernels inside the whole model."""
+    from src.models.backpack import BackpackConfig, BackpackLMHeadModel
+    kw = dict(n_embd=640, n_head=8, n_layer=2, num_content_vectors=64, shrink_final_inner=True)
+    cfg = BackpackConfig(vocab_size=4093, n_positions=192, scale_attn_by_inverse_layer_idx=True, resid_pdrop=0.0,
+                         embd_pdrop=0.0, attn_pdrop=0.0, use_flash_attn=True, pad_vocab_size_multiple=8,
+                         fused_dropout_add_ln=fused, fused_dense_gelu_dense=fused, fused_bias_fc=fused, **kw)
+    torch.manual_seed(1)
+    model = BackpackLMHeadModel(cfg).eval()
+    with torch.no_grad():
+        model.transformer.contextualization_attn.Wqkv.weight.mul_(8.0)
+        for layer in model.transformer.gpt2_model.layers:
+            layer.mixer.Wqkv.weight.mul_(6.0)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ids = torch.randint(0, 4093, (2, 192), generator=torch.Generator().manual_seed(1))
+    ocfg = dict(layer_norm_epsilon=1e-5, scale_attn_by_inverse_layer_idx=True, **kw)
+    want = R.backpack_forward(sd, ocfg, ids, return_stages=True)
+    eager = R.backpack_forward({k: v.bfloat16() for k, v in sd.items()}, ocfg, ids, return_stages=True)
+    model = model.to(DEV, torch.bfloat16)
+    with torch.no_grad():
+        hidden = model.transformer(ids.to(DEV))
+        logits = model(ids.to(DEV)).logits
+    for got, name in ((hidden, 'hidden'), (logits, 'logits')):
+        err = (got.float().cpu() - want[name]).abs().max().item()
+        base = (eager[name].float() - want[name]).abs().max().item()
+        print(f'mini-k64 {name}: hip {err:.3e} eager {base:.3e}')
+        assert err <= 3 * base + 1e-3, (name, err, base)
+
+
 def test_interface_functions_and_probs():
     from flash_attn.flash_attn_interface import (flash_attn_unpadded_func,
                                                  flash_attn_unpadded_kvpacked_func,
@@ -151,3 +183,24 @@ def test_autograd_through_the_forward_kernel():
     ref_in = qkv.detach().float().requires_grad_()
     (dref,) = torch.autograd.grad(SelfAttention(causal=True)(ref_in), ref_in, g.float())
     assert (dqkv.float() - dref).abs().max().item() < 5e-2
+
+
+def test_hip_graph_replay_matches_eager_launches():
+    """The whole forward (torch ops + C-ABI launches) captured in a HIP graph replays bit-identically and
+    follows new inputs through the static buffer."""
+    import bp_hip
+    from src.models.backpack import BackpackConfig, BackpackLMHeadModel
+    cfg = BackpackConfig(n_embd=384, n_head=6, n_layer=2, num_content_vectors=16, vocab_size=1000,
+                         n_positions=128, scale_attn_by_inverse_layer_idx=True, resid_pdrop=0.0,
+                         embd_pdrop=0.0, attn_pdrop=0.0, use_flash_attn=True, pad_vocab_size_multiple=8,
+                         fused_dropout_add_ln=True, fused_dense_gelu_dense=True, fused_bias_fc=True)
+    torch.manual_seed(3)
+    model = BackpackLMHeadModel(cfg).eval().to(DEV, torch.bfloat16)
+    ids_a = torch.randint(0, 1000, (4, 128), device=DEV)
+    ids_b = torch.randint(0, 1000, (4, 128), device=DEV)
+    fwd = bp_hip.GraphedForward(model, ids_a)
+    with torch.no_grad():
+        want_a, want_b = model(ids_a).logits, model(ids_b).logits
+    assert torch.equal(fwd(ids_a), want_a)
+    assert torch.equal(fwd(ids_b), want_b)
+    assert not torch.equal(want_a, want_b)
