@@ -29,6 +29,7 @@ SIGNATURES = {
     'bp_sense_lse': (_i32, [_ptr] * 2 + [_i32] * 4 + [_i64] * 4 + [_f32, _i32, _ptr]),
     'bp_sense_alpha': (_i32, [_ptr] * 3 + [_i32] * 5 + [_i64] * 4 + [_f32, _i32, _ptr]),
     'bp_sense_mix': (_i32, [_ptr] * 4 + [_i32] * 6 + [_i64] * 9 + [_f32, _i32, _ptr]),
+    'bp_sense_mix_weighted': (_i32, [_ptr] * 5 + [_i32] * 6 + [_i64] * 11 + [_f32, _i32, _ptr]),
     'bp_add_layer_norm': (_i32, [_ptr] * 6 + [_i64, _i32, _f32] + [_i32] * 4 + [_ptr]),
 }
 
@@ -247,12 +248,15 @@ def sense_alpha(qk, softmax_scale=None, lse=None):
     return alpha
 
 
-def sense_mix(qk, content, softmax_scale=None, out=None, lse=None):
+def sense_mix(qk, content, softmax_scale=None, out=None, lse=None, key_weight=None):
     """Fused sum_l softmax_causal(q_l k_l^T * scale) @ C_l without materialising alpha.
 
     qk (B,S,2,k,d_k); content in its storage layout (B,S,k,d_out) (the reference's
     `content` (B,k,S,d_out) is `.transpose(1,2)` of it -- pass that view transposed back, it is
-    free); returns (B,S,d_out).  Replaces backpack.py:305+313."""
+    free); returns (B,S,d_out).  Replaces backpack.py:305+313.
+    key_weight (B,k,S), optional: alpha[b,l,:,s] (= content row s of sense l) is scaled by
+    key_weight[b,l,s] inside the kernel -- the intervention hook of intervened_models.py:97-101 and
+    test_genderbias.py:71-78 (C ABI bp_sense_mix_weighted)."""
     b, s, k, dk = _check_qk(qk)
     _require_cuda(content)
     if content.dim() != 4 or content.shape[:3] != (b, s, k) or content.stride(-1) != 1:
@@ -266,14 +270,23 @@ def sense_mix(qk, content, softmax_scale=None, out=None, lse=None):
     if out is None:
         out = torch.empty((b, s, dout), dtype=qk.dtype, device=qk.device)
     ws, ready = _lse_ws(qk, lse, b, s, k)
+    kw = None
+    if key_weight is not None:
+        _require_cuda(key_weight)
+        if key_weight.shape != (b, k, s):
+            raise RuntimeError('bp_hip.sense_mix: key_weight must be (B, k, S)')
+        kw = key_weight.to(torch.float32)
+        if kw.stride(-1) != 1:
+            kw = kw.contiguous()
     with torch.cuda.device(qk.device):
-        code = lib().bp_sense_mix(qk.data_ptr(), content.data_ptr(), out.data_ptr(), ws.data_ptr(),
-                                  ready, b, s, k, dk, dout,
-                                  qk.stride(0), qk.stride(1), qk.stride(2), qk.stride(3),
-                                  content.stride(0), content.stride(1), content.stride(2),
-                                  out.stride(0), out.stride(1),
-                                  float(scale), _dtype_code(qk), _stream())
-    _check(code, 'bp_sense_mix')
+        code = lib().bp_sense_mix_weighted(
+            qk.data_ptr(), content.data_ptr(), kw.data_ptr() if kw is not None else None, out.data_ptr(),
+            ws.data_ptr(), ready, b, s, k, dk, dout,
+            qk.stride(0), qk.stride(1), qk.stride(2), qk.stride(3),
+            content.stride(0), content.stride(1), content.stride(2),
+            kw.stride(0) if kw is not None else 0, kw.stride(1) if kw is not None else 0,
+            out.stride(0), out.stride(1), float(scale), _dtype_code(qk), _stream())
+    _check(code, 'bp_sense_mix_weighted')
     return out
 
 

@@ -201,6 +201,21 @@ int bp_sense_mix(const void *qk, const void *content, void *out, float *lse_ws, 
                  int64_t c_batch_stride, int64_t c_row_stride, int64_t c_sense_stride,
                  int64_t o_batch_stride, int64_t o_row_stride,
                  float softmax_scale, int dtype, bp_stream_t stream) {
+    return bp_sense_mix_weighted(qk, content, nullptr, out, lse_ws, lse_ready, batch, seqlen, nsenses, d_k, d_out,
+                                 qk_batch_stride, qk_row_stride, qk_two_stride, qk_sense_stride, c_batch_stride,
+                                 c_row_stride, c_sense_stride, 0, 0, o_batch_stride, o_row_stride, softmax_scale,
+                                 dtype, stream);
+}
+
+int bp_sense_mix_weighted(const void *qk, const void *content, const float *key_weight, void *out,
+                          float *lse_ws, int lse_ready,
+                          int batch, int seqlen, int nsenses, int d_k, int d_out,
+                          int64_t qk_batch_stride, int64_t qk_row_stride, int64_t qk_two_stride,
+                          int64_t qk_sense_stride,
+                          int64_t c_batch_stride, int64_t c_row_stride, int64_t c_sense_stride,
+                          int64_t kw_batch_stride, int64_t kw_sense_stride,
+                          int64_t o_batch_stride, int64_t o_row_stride,
+                          float softmax_scale, int dtype, bp_stream_t stream) {
     if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
     if (d_k < 1 || d_k > 128) return BP_ERR_HEAD_DIM;
     if (d_out < 1) return BP_ERR_DOUT;
@@ -217,6 +232,7 @@ int bp_sense_mix(const void *qk, const void *content, void *out, float *lse_ws, 
     const uint16_t *qp = static_cast<const uint16_t *>(qk);
     bp::MixParams p{};
     p.q = qp; p.k = qp + qk_two_stride; p.c = content; p.o = out; p.lse = lse_ws;
+    p.kw = key_weight; p.kw_bs = kw_batch_stride; p.kw_ss = kw_sense_stride;
     p.qk_bs = qk_batch_stride; p.qk_rs = qk_row_stride; p.qk_ss = qk_sense_stride;
     p.c_bs = c_batch_stride; p.c_rs = c_row_stride; p.c_ss = c_sense_stride;
     p.o_bs = o_batch_stride; p.o_rs = o_row_stride;

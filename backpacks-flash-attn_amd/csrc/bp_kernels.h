@@ -57,6 +57,8 @@ struct MixParams {
     const void *c;            // content[b, s, l, :] = c + b*c_bs + s*c_rs + l*c_ss
     void *o;                  // out[b, t, :] = o + b*o_bs + t*o_rs
     const float *lse;         // (b, k, lse_stride) natural-log LSE of every (sense, query)
+    const float *kw;          // optional key weights w[b, l, s] (fp32, unit stride along s): alpha[b,l,:,s] *= w
+    int64_t kw_bs, kw_ss;
     int64_t qk_bs, qk_rs, qk_ss;
     int64_t c_bs, c_rs, c_ss;
     int64_t o_bs, o_rs;

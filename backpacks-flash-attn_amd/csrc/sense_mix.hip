@@ -173,13 +173,13 @@ __global__ __launch_bounds__(512) void sense_mix_kernel(const MixParams p) {
                 st = E::mfma(a, qf[s], st);
             }
             const bool diag = (kb == my_last_kb);
+            const float *kw = p.kw != nullptr ? p.kw + batch * p.kw_bs + (int64_t)l * p.kw_ss : nullptr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float e = fast_exp2(fmaf(st[r], c2, -lse2));
-                if (diag) {
-                    const int key = kb * C::BK + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    if (key > my_q) e = 0.f;
-                }
+                const int key = kb * C::BK + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (diag && key > my_q) e = 0.f;
+                if (kw != nullptr) e *= kw[min(key, S - 1)];   // intervention hook: alpha[:, key] scaled
                 st[r] = e;
             }
 #pragma unroll

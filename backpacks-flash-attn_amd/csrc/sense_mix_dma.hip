@@ -42,7 +42,7 @@
 
 namespace bp {
 
-template <int KD>
+template <int KD, bool WEIGHTED = false>
 struct MixDmaCfg {
     static constexpr int BM = 256, BK = 64, NB = 8, BNC = 256, NT = 512, NWAVE = 8, NSTAGE = 3;
     static constexpr int KROW = KD <= 4 ? 128 : 256;   // bytes per K row (power of two, XOR-swizzled)
@@ -50,10 +50,11 @@ struct MixDmaCfg {
     static constexpr int CROW = 512;
     static constexpr int KTILE = BK * KROW;
     static constexpr int CTILE = BK * CROW;
-    static constexpr int STAGE = KTILE + CTILE;
+    static constexpr int WTILE = WEIGHTED ? NWAVE * 256 : 0;   // per wave: the tile's 64 key weights (fp32)
+    static constexpr int STAGE = KTILE + CTILE + WTILE;
     static constexpr int K_DMA = KTILE / 1024 / NWAVE;   // DMA instructions per wave per tile (1 or 2)
     static constexpr int C_DMA = CTILE / 1024 / NWAVE;   // 4
-    static constexpr int DMA_PER_STAGE = K_DMA + C_DMA;
+    static constexpr int DMA_PER_STAGE = K_DMA + C_DMA + (WEIGHTED ? 1 : 0);
     static constexpr int K_ROWS_PER_DMA = 1024 / KROW;   // 8 or 4
 #ifndef BP_MIX_SUPER
 #define BP_MIX_SUPER 0   // measured slower on MI355X (see the header comment); kept as an A/B build switch
@@ -70,9 +71,9 @@ struct MixCursor {
     int st, l, kk;
 };
 
-template <class ET, int KD, bool FULL>
+template <class ET, int KD, bool FULL, bool WEIGHTED>
 __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
-    using C = MixDmaCfg<KD>;
+    using C = MixDmaCfg<KD, WEIGHTED>;
     using E = Elem<ET>;
     __shared__ __attribute__((aligned(16))) char smem[C::SMEM];
 
@@ -193,6 +194,10 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
             const int key = min(kb * C::BK + k_row[j], S - 1);
             const uint16_t *src = kg + (int64_t)l * p.qk_ss + (int64_t)key * p.qk_rs + k_col[j];
             if (k_on[j]) dma16_d(src, stage_off + (wave * C::K_DMA + j) * 1024);
+        } else if (WEIGHTED && j == C::K_DMA + C::C_DMA) {
+            // key weights of this (sense, tile): lane i fetches w[key0 + i] into the wave's own 256-B slot
+            const float *src = p.kw + batch * p.kw_bs + (int64_t)l * p.kw_ss + min(kb * C::BK + lane, S - 1);
+            dma4(src, stage_off + C::KTILE + C::CTILE + wave * 256);
         } else {
             const int jc = j - C::K_DMA;
             const int key = min(kb * C::BK + c_row[jc], S - 1);
@@ -349,6 +354,20 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) st[r] = lse2;
 #endif
+                    if (WEIGHTED) {
+                        // intervention hook: alpha[b, l, :, key] *= w[b, l, key]  (register r holds key
+                        // (r & 3) + 8 (r >> 2) + 4 hh of the sub-block: four runs of four consecutive keys)
+                        const int wbase = stage_off + C::KTILE + C::CTILE + wave * 256 + (kk * 32 + 4 * hh) * 4;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const u32x4 w4 = lds_read_16B(smem, wbase + g * 32);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const uint32_t wi = w4[i];   // by-value copy (bp_common.h, as_f32)
+                                st[4 * g + i] *= as_f32(wi);
+                            }
+                        }
+                    }
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -403,8 +422,11 @@ static hipError_t launch_kd(const MixParams &p, hipStream_t stream) {
     const int grid = p.order >= 2 ? ((p.b + 7) / 8) * 8 * p.n_chunks * p.n_qtiles
                                   : xcd_grid(p.b * p.n_chunks, p.n_qtiles);
     dim3 g(grid), t(512);
-    if (p.dout % 256 == 0) hipLaunchKernelGGL((sense_mix_dma_kernel<ET, KD, true>), g, t, 0, stream, p);
-    else hipLaunchKernelGGL((sense_mix_dma_kernel<ET, KD, false>), g, t, 0, stream, p);
+    if (p.kw != nullptr) {
+        if (p.dout % 256 == 0) hipLaunchKernelGGL((sense_mix_dma_kernel<ET, KD, true, true>), g, t, 0, stream, p);
+        else hipLaunchKernelGGL((sense_mix_dma_kernel<ET, KD, false, true>), g, t, 0, stream, p);
+    } else if (p.dout % 256 == 0) hipLaunchKernelGGL((sense_mix_dma_kernel<ET, KD, true, false>), g, t, 0, stream, p);
+    else hipLaunchKernelGGL((sense_mix_dma_kernel<ET, KD, false, false>), g, t, 0, stream, p);
     return hipGetLastError();
 }
 

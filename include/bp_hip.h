@@ -134,6 +134,30 @@ int bp_sense_mix(const void *qk, const void *content, void *out, float *lse_ws, 
                  float softmax_scale, int dtype, bp_stream_t stream);
 
 /*
+ * bp_sense_mix_weighted -- bp_sense_mix with the intervention hook fused in:
+ *   out[b,t,:] = sum_l sum_{s<=t} alpha[b,l,t,s] * key_weight[b,l,s] * content[b,s,l,:]
+ * i.e. column s of sense l's contextualisation (equivalently: row s of that sense's content) is
+ * scaled before the contraction.  Covers, without materialising alpha or a re-weighted copy of the
+ * content, the reference's control experiments:
+ *   - `contextualization[0, vector_index, :, index] *= percent` then `sum(contextualization @ content)`
+ *     (training/src/test_genderbias.py:71-78),
+ *   - `content * content_weights.transpose(1,2).unsqueeze(3)` then the same contraction
+ *     (training/src/models/intervened_models.py:97-101).
+ *   key_weight  (batch, nsenses, seqlen) fp32, unit stride along seqlen, element strides
+ *               kw_batch/kw_sense; NULL = no weighting (then identical to bp_sense_mix)
+ * All other arguments as bp_sense_mix.
+ */
+int bp_sense_mix_weighted(const void *qk, const void *content, const float *key_weight, void *out,
+                          float *lse_ws, int lse_ready,
+                          int batch, int seqlen, int nsenses, int d_k, int d_out,
+                          int64_t qk_batch_stride, int64_t qk_row_stride, int64_t qk_two_stride,
+                          int64_t qk_sense_stride,
+                          int64_t c_batch_stride, int64_t c_row_stride, int64_t c_sense_stride,
+                          int64_t kw_batch_stride, int64_t kw_sense_stride,
+                          int64_t o_batch_stride, int64_t o_row_stride,
+                          float softmax_scale, int dtype, bp_stream_t stream);
+
+/*
  * bp_flash_bwd -- attention backward: dq, dk, dv from q, k, v, dout and the forward's out and softmax_lse.
  * Replaces flash_attn_cuda.bwd / mha_bwd (csrc/flash_attn/fmha_api.cpp:337-504) called by
  * _flash_attn_backward (flash_attn/flash_attn_interface.py:31-47), no-dropout path.  P is recomputed

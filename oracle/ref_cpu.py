@@ -333,3 +333,80 @@ def make_config(name, n_positions=1024, vocab_size=50264):
     cfg.update(n_positions=n_positions, vocab_size=vocab_size, layer_norm_epsilon=1e-5,
                scale_attn_by_inverse_layer_idx=True)
     return cfg
+
+
+# ---------------------------------------------------------------------------------------------
+# Control experiments built on the sense contraction:
+# training/src/models/intervened_models.py.  Restated with the reference's own tensor algebra
+# (full-vocabulary gather included) so the product's cheaper formulations are checked against it.
+# ---------------------------------------------------------------------------------------------
+def content_soft_mask(content_weights, input_ids, scores):
+    """intervened_models.py:9-20.  content_weights (V, k), input_ids (B, S), scores (B, S, k)
+    -> per-token, per-sense weights (B, S, k): w * score + (1 - score)."""
+    picked = content_weights[input_ids]                                  # gather over the vocabulary axis
+    return picked * scores + torch.ones_like(picked) * (1 - scores)
+
+
+def mask_annealing_scores(lm_head_weight, input_ids, content, annealing_scale=0.1, upweight_nearby=True):
+    """intervened_models.py:29-53.  content (B, k, S, d) -> scores (B, k, S):
+    sigmoid(-scale * sum_j relu(content[b,l,i] . E[ids[b,j]]) + 6), optionally x (1 + i/100)."""
+    b, s = input_ids.shape
+    vocab_logits = torch.relu(content @ lm_head_weight.t())              # (B, k, S, V)
+    index = input_ids.reshape(b, 1, 1, s).expand(-1, content.shape[1], s, -1)
+    sims = torch.gather(vocab_logits, dim=3, index=index)               # (B, k, S, S)
+    sims = torch.where(sims > 0.0, sims, torch.zeros_like(sims)).sum(dim=3)
+    scores = torch.sigmoid(-annealing_scale * sims + 6)
+    if upweight_nearby:
+        scores = scores * (1 + torch.arange(s) / 100).reshape(1, 1, s)
+    return scores
+
+
+def _intervention_stages(sd, cfg, input_ids):
+    st = backpack_forward(sd, cfg, input_ids, return_stages=True)
+    return st['alpha'], st['content'], sd['lm_head.weight']
+
+
+def weighted_backpack_logits(sd, cfg, input_ids, content_weights, annealing_scale=0.1, anneal=True,
+                             upweight_nearby=True):
+    """WeightedBackpackLMHeadModel.forward, intervened_models.py:70-105."""
+    alpha, content, w_lm = _intervention_stages(sd, cfg, input_ids)
+    if anneal:
+        scores = mask_annealing_scores(w_lm, input_ids, content, annealing_scale, upweight_nearby).transpose(1, 2)
+    else:
+        scores = torch.ones(content.shape[0], content.shape[2], content.shape[1])
+    weights = content_soft_mask(content_weights, input_ids, scores)       # (B, S, k)
+    content = content * weights.transpose(1, 2).unsqueeze(3)
+    hidden = torch.sum(alpha @ content, dim=1)
+    return hidden @ w_lm.t()
+
+
+def negative_weighted_backpack_logits(sd, cfg, input_ids, content_weights, annealing_scale=0.1, anneal=True,
+                                      upweight_nearby=True):
+    """NegativeWeightedBackpackLMHeadModel.forward, intervened_models.py:120-165: per (sense, position) the
+    2 % most negative re-weighted vocabulary logits replace the plain ones; the contraction runs on
+    vocabulary-sized content."""
+    alpha, content, w_lm = _intervention_stages(sd, cfg, input_ids)
+    if anneal:
+        scores = mask_annealing_scores(w_lm, input_ids, content, annealing_scale, upweight_nearby).transpose(1, 2)
+    else:
+        scores = torch.ones(content.shape[0], content.shape[2], content.shape[1])
+    weights = content_soft_mask(content_weights, input_ids, scores)
+    weighted = content * weights.transpose(1, 2).unsqueeze(3)
+    logits_c = content @ w_lm.t()
+    logits_w = weighted @ w_lm.t()
+    q = torch.quantile(logits_w.float(), q=0.02, keepdim=True, dim=-1)
+    logits_c = torch.where(logits_w < q, logits_w, logits_c)
+    return torch.sum(alpha @ logits_c, dim=1)
+
+
+def replaced_word_logits(sd, cfg, input_ids, sense_dict):
+    """ReplacedWordLMHeadModel.forward, intervened_models.py:175-199: every position whose token is a
+    key of `sense_dict` gets that entry's (k, d) sense vectors instead of its own."""
+    alpha, content, w_lm = _intervention_stages(sd, cfg, input_ids)
+    content = content.clone()
+    for bi in range(content.shape[0]):
+        for si in range(content.shape[2]):
+            word = int(input_ids[bi, si])
+            if word in sense_dict:
+                content[bi, :, si, :] = sense_dict[word]
+    return torch.sum(alpha @ content, dim=1) @ w_lm.t()

@@ -226,6 +226,60 @@ def main():
         g5[f'lse_causal{int(causal)}'] = np.concatenate([np32(l) for l in lv], axis=1)
     np.savez_compressed(os.path.join(HERE, 'g5_varlen.npz'), **g5)
 
+    # ---- G6: the control-experiment models of intervened_models.py on a 16-sense nano model ---------
+    sys.path.insert(0, os.path.join(REF, 'training', 'src'))
+    import src.models.intervened_models as im
+    nano16 = dict(nano, num_content_vectors=16)
+    torch.manual_seed(6)
+    cfg6, model6 = build(nano16)
+    with torch.no_grad():
+        model6.transformer.contextualization_attn.Wqkv.weight.mul_(8.0)
+        model6.transformer.content_model.final_mlp.fc2.weight.mul_(6.0)   # content logits large enough to anneal
+    ids6 = torch.randint(0, 96, (2, 32), generator=torch.Generator().manual_seed(6))
+    sd6 = {k: v.detach().clone() for k, v in model6.state_dict().items()}
+    gen6 = torch.Generator().manual_seed(66)
+    content_weights = torch.rand(96, 16, generator=gen6) * 2.0
+    sense_dict = {int(ids6[0, 3]): torch.randn(16, 64, generator=gen6), int(ids6[1, 20]): torch.randn(16, 64, generator=gen6)}
+
+    def make(cls, **attrs):
+        # the constructors move a tensor to 'cuda'; build the object without running them (forward untouched)
+        obj = cls.__new__(cls)
+        torch.nn.Module.__init__(obj)
+        for k, v in attrs.items():
+            setattr(obj, k, v)
+        return obj
+
+    common = dict(backpack_network=model6, content_weights=content_weights, target_weight=torch.zeros(96),
+                  annealing_scale=30.0, upweight_nearby=True)   # sims are 0.04..0.4 here: spans the sigmoid
+    ocfg6 = dict(n_embd=64, n_head=2, n_layer=2, num_content_vectors=16, layer_norm_epsilon=cfg6.layer_norm_epsilon,
+                 scale_attn_by_inverse_layer_idx=True)
+    g6 = {('sd/' + k): np32(v) for k, v in sd6.items()}
+    g6.update(ids=ids6.numpy(), content_weights=np32(content_weights),
+              sense_words=np.array(sorted(sense_dict)), layer_norm_epsilon=np.float64(cfg6.layer_norm_epsilon),
+              annealing_scale=np.float64(30.0))
+    for w in sorted(sense_dict):
+        g6['sense/%d' % w] = np32(sense_dict[w])
+    with torch.no_grad():
+        for tag, anneal in (('anneal', True), ('plain', False)):
+            want = make(im.WeightedBackpackLMHeadModel, anneal=anneal, **common)(ids6).logits
+            got = R.weighted_backpack_logits(sd6, ocfg6, ids6, content_weights, annealing_scale=30.0, anneal=anneal)
+            check('G6 weighted ' + tag, got, want, 5e-5)
+            g6['weighted_' + tag] = np32(want)
+            want = make(im.NegativeWeightedBackpackLMHeadModel, anneal=anneal, **common)(ids6).logits
+            got = R.negative_weighted_backpack_logits(sd6, ocfg6, ids6, content_weights, annealing_scale=30.0,
+                                                      anneal=anneal)
+            check('G6 negative ' + tag, got, want, 5e-5)
+            g6['negative_' + tag] = np32(want)
+        content6 = model6.transformer.content_model(ids6)
+        scores = im.mask_annealing(model6, ids6, torch.zeros(96), content6, 30.0, True)
+        check('G6 annealing scores', R.mask_annealing_scores(sd6['lm_head.weight'], ids6, content6, 30.0), scores, 1e-6)
+        g6['annealing_scores'] = np32(scores)
+        want = make(im.ReplacedWordLMHeadModel, backpack_network=model6, sense_dict=sense_dict)(ids6).logits
+        got = R.replaced_word_logits(sd6, ocfg6, ids6, sense_dict)
+        check('G6 replaced words', got, want, 5e-5)
+        g6['replaced'] = np32(want)
+    np.savez_compressed(os.path.join(HERE, 'g6_interventions.npz'), **g6)
+
     with open(os.path.join(HERE, 'PINNING.txt'), 'w') as f:
         f.write('oracle/ref_cpu.py checked against the imported reference (torch %s)\n' % torch.__version__)
         f.write('\n'.join(log) + '\n')

@@ -358,6 +358,32 @@ def test_sense_mix_intervention_shapes():
     rel_check(out3, want3, eager3, 'mix vocab-sized')
 
 
+@pytest.mark.parametrize('shape', [
+    (2, 200, 16, 48, 768),     # fast (LDS-DMA) path, two query tiles
+    (1, 96, 4, 24, 100),       # generic path (d_out % 8 != 0)
+    (2, 130, 64, 10, 640),     # zero-padded d_k = 10
+])
+def test_sense_mix_key_weight_hook(shape):
+    """bp_sense_mix_weighted: alpha[b,l,:,s] * w[b,l,s] fused == the reference's eager edit of alpha
+    (test_genderbias.py:71-78) == re-weighting the content rows (intervened_models.py:97-101)."""
+    bp = _bp()
+    b, s, k, dk, d = shape
+    torch.manual_seed(31)
+    qk = (torch.randn(b, s, 2, k, dk) * 1.2).bfloat16()
+    c = torch.randn(b, s, k, d).bfloat16()
+    w = torch.rand(b, k, s) * 2.0
+    w[:, 1, s // 2] = 0.0                                      # a knocked-out (sense, token)
+    alpha = R.sense_alpha_from_qk(qk.float())                   # (B,k,S,S) fp32
+    want = R.sense_mix(alpha * w.unsqueeze(2), c.float().transpose(1, 2))
+    weighted_c = (c.float() * w.transpose(1, 2).unsqueeze(3)).bfloat16()
+    eager = R.sense_mix(R.sense_alpha_from_qk(qk), weighted_c.transpose(1, 2))
+    out = bp.sense_mix(qk.to(DEV), c.to(DEV), key_weight=w.to(DEV))
+    rel_check(out, want, eager, f'mix key_weight {shape}', atol=2e-3)
+    plain = bp.sense_mix(qk.to(DEV), c.to(DEV))
+    ones = bp.sense_mix(qk.to(DEV), c.to(DEV), key_weight=torch.ones(b, k, s, device=DEV))
+    assert torch.equal(plain, ones)                             # weight 1 is exactly the unweighted kernel
+
+
 # ---------------------------------------------------------------------------------------------
 # BASELINE config 5 shape (S = 4096, fp16): oracle on a subset of query rows (full key range)
 # ---------------------------------------------------------------------------------------------

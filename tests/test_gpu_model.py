@@ -204,3 +204,43 @@ def test_hip_graph_replay_matches_eager_launches():
     assert torch.equal(fwd(ids_a), want_a)
     assert torch.equal(fwd(ids_b), want_b)
     assert not torch.equal(want_a, want_b)
+
+
+def test_intervened_models_hip_vs_oracle():
+    """Mirror of intervened_models.py on the HIP path (fused key-weight hook, vocabulary-sized content) in
+    bf16 against the fp32 oracle restatement, with the eager-bf16 error as yardstick."""
+    from src.models import intervened_models as im
+    from src.models.backpack import BackpackConfig, BackpackLMHeadModel
+    g = load_golden('g6_interventions.npz')
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd/')}
+    ids = torch.from_numpy(g['ids'])
+    cw = torch.from_numpy(g['content_weights'])
+    senses = {int(w): torch.from_numpy(g['sense/%d' % w]) for w in g['sense_words']}
+    scale = float(g['annealing_scale'])
+    kw = dict(n_embd=64, n_head=2, n_layer=2, num_content_vectors=16, vocab_size=96, n_positions=32,
+              scale_attn_by_inverse_layer_idx=True, resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0,
+              pad_vocab_size_multiple=8)
+    hip = BackpackLMHeadModel(BackpackConfig(use_flash_attn=True, **kw)).eval()
+    hip.load_state_dict(sd, strict=True)
+    hip = hip.to(DEV, torch.bfloat16)
+    eager = BackpackLMHeadModel(BackpackConfig(use_flash_attn=False, **kw)).eval()
+    eager.load_state_dict(sd, strict=True)
+    eager = eager.to(torch.bfloat16)
+    cases = [('weighted_anneal', im.WeightedBackpackLMHeadModel, dict(anneal=True)),
+             ('weighted_plain', im.WeightedBackpackLMHeadModel, dict(anneal=False)),
+             ('negative_plain', im.NegativeWeightedBackpackLMHeadModel, dict(anneal=False))]
+    with torch.no_grad():
+        for name, cls, opt in cases:
+            got = cls(hip, cw.to(DEV), torch.zeros(96), scale, **opt)(ids.to(DEV)).logits
+            base = cls(eager, cw, torch.zeros(96), scale, **opt)(ids).logits
+            want = torch.from_numpy(g[name])
+            err = (got.float().cpu() - want).abs().max().item()
+            ref = (base.float() - want).abs().max().item()
+            print(f'{name}: hip {err:.3e} eager-bf16 {ref:.3e}')
+            assert err <= 3 * ref + 2e-3, (name, err, ref)
+        got = im.ReplacedWordLMHeadModel(hip, senses)(ids.to(DEV)).logits
+        base = im.ReplacedWordLMHeadModel(eager, senses)(ids).logits
+        want = torch.from_numpy(g['replaced'])
+        err, ref = (got.float().cpu() - want).abs().max().item(), (base.float() - want).abs().max().item()
+        print(f'replaced: hip {err:.3e} eager-bf16 {ref:.3e}')
+        assert err <= 3 * ref + 2e-3

@@ -180,3 +180,39 @@ def test_generation_and_checkpoint_roundtrip(tmp_path):
     assert model.sample(ids, max_length=8).shape == (1, 8)
     batch = greedy_decode(torch.cat([ids, ids]), model, 8).sequences
     assert torch.equal(batch[0], batch[1]) and torch.equal(batch[0], seq[0, :8])
+
+
+def _g6():
+    g = load_golden('g6_interventions.npz')
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd/')}
+    ids = torch.from_numpy(g['ids'])
+    cw = torch.from_numpy(g['content_weights'])
+    senses = {int(w): torch.from_numpy(g['sense/%d' % w]) for w in g['sense_words']}
+    return g, sd, ids, cw, senses
+
+
+def test_intervened_models_match_reference_golden_on_cpu():
+    """The mirror of intervened_models.py (eager path here) against logits produced by the REFERENCE classes
+    (tests/golden/make_golden.py G6): weighted / negative-weighted with and without annealing, replaced words."""
+    from src.models import intervened_models as im
+    g, sd, ids, cw, senses = _g6()
+    model = BackpackLMHeadModel(nano_config(num_content_vectors=16)).eval()
+    model.load_state_dict(sd, strict=True)
+    scale = float(g['annealing_scale'])
+    with torch.no_grad():
+        content = model.transformer.content_model(ids)
+        scores = im.mask_annealing(model, ids, None, content, scale, True)
+        assert (scores - torch.from_numpy(g['annealing_scores'])).abs().max().item() < 1e-5
+        for tag, anneal in (('anneal', True), ('plain', False)):
+            w = im.WeightedBackpackLMHeadModel(model, cw, torch.zeros(96), scale, anneal=anneal)
+            assert (w(ids).logits - torch.from_numpy(g['weighted_' + tag])).abs().max().item() < 1e-4, tag
+            n = im.NegativeWeightedBackpackLMHeadModel(model, cw, torch.zeros(96), scale, anneal=anneal)
+            assert (n(ids).logits - torch.from_numpy(g['negative_' + tag])).abs().max().item() < 1e-4, tag
+        r = im.ReplacedWordLMHeadModel(model, senses)
+        assert (r(ids).logits - torch.from_numpy(g['replaced'])).abs().max().item() < 1e-4
+        # a sense vector does not depend on context or position
+        v = im.get_sense_vector_of_word(int(ids[0, 3]), model, 5)
+        assert (v - content[0, 5, 3, :]).abs().max().item() < 1e-5
+    assert list(inspect.signature(im.WeightedBackpackLMHeadModel.__init__).parameters)[1:] == [
+        'backpack_network', 'content_weights', 'target_weight', 'annealing_scale', 'anneal', 'upweight_nearby']
+    assert list(inspect.signature(im.create_content_soft_mask).parameters) == ['content_weights', 'input_ids', 'scores']

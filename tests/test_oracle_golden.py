@@ -89,3 +89,22 @@ def test_init_state_dict_matches_reference_parameter_count():
     sd = R.init_state_dict(cfg)
     n = sum(v.numel() for k, v in sd.items() if k != 'lm_head.weight')
     assert n == 170_482_944 or abs(n - 170.48e6) < 0.02e6, n   # README.md:89 "170M", SURVEY 8c
+
+
+def test_intervention_oracle_against_reference_golden():
+    """oracle/ref_cpu.py restatement of intervened_models.py vs the logits of the reference classes (G6)."""
+    g = load_golden('g6_interventions.npz')
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd/')}
+    ids = torch.from_numpy(g['ids'])
+    cw = torch.from_numpy(g['content_weights'])
+    cfg = dict(n_embd=64, n_head=2, n_layer=2, num_content_vectors=16,
+               layer_norm_epsilon=float(g['layer_norm_epsilon']), scale_attn_by_inverse_layer_idx=True)
+    scale = float(g['annealing_scale'])
+    for tag, anneal in (('anneal', True), ('plain', False)):
+        got = R.weighted_backpack_logits(sd, cfg, ids, cw, annealing_scale=scale, anneal=anneal)
+        assert (got - torch.from_numpy(g['weighted_' + tag])).abs().max().item() < 5e-5
+        got = R.negative_weighted_backpack_logits(sd, cfg, ids, cw, annealing_scale=scale, anneal=anneal)
+        assert (got - torch.from_numpy(g['negative_' + tag])).abs().max().item() < 5e-5
+    senses = {int(w): torch.from_numpy(g['sense/%d' % w]) for w in g['sense_words']}
+    got = R.replaced_word_logits(sd, cfg, ids, senses)
+    assert (got - torch.from_numpy(g['replaced'])).abs().max().item() < 5e-5
