@@ -31,6 +31,8 @@ SIGNATURES = {
     'bp_sense_mix': (_i32, [_ptr] * 4 + [_i32] * 6 + [_i64] * 9 + [_f32, _i32, _ptr]),
     'bp_sense_mix_weighted': (_i32, [_ptr] * 5 + [_i32] * 6 + [_i64] * 11 + [_f32, _i32, _ptr]),
     'bp_add_layer_norm': (_i32, [_ptr] * 6 + [_i64, _i32, _f32] + [_i32] * 4 + [_ptr]),
+    'bp_xentropy_fwd': (_i32, [_ptr] * 4 + [_i64, _i32, _i64, _f32, _i32, _i32, _ptr]),
+    'bp_xentropy_bwd': (_i32, [_ptr] * 5 + [_i64, _i32, _i64, _i64, _f32, _i32, _i32, _ptr]),
 }
 
 
@@ -326,6 +328,47 @@ def add_layer_norm(x0, x1, weight, bias, eps, residual_dtype=None, return_residu
             int(weight.dtype == torch.float32), _stream())
     _check(code, 'bp_add_layer_norm')
     return (z, xo) if return_residual else z
+
+
+def _xent_dtype(t):
+    code = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}.get(t.dtype)
+    if code is None:
+        raise RuntimeError(f'bp_hip: cross entropy takes fp16 / bf16 / fp32 logits, got {t.dtype}')
+    return code
+
+
+def xentropy_fwd(logits, labels, smoothing=0.0, total_classes=-1):
+    """(losses, lse), both fp32 (rows,): the reference's xentropy_cuda_lib.forward
+    (flash_attn/losses/cross_entropy.py:37,54).  logits (rows, cols), last dim contiguous; labels int64."""
+    _require_cuda(logits, labels)
+    if logits.dim() != 2 or logits.stride(1) != 1 or labels.shape != (logits.shape[0],):
+        raise RuntimeError('bp_hip.xentropy_fwd: logits (rows, cols) with unit last stride, labels (rows,)')
+    labels = labels.to(torch.int64).contiguous()
+    rows, cols = logits.shape
+    losses = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    lse = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    with torch.cuda.device(logits.device):
+        code = lib().bp_xentropy_fwd(logits.data_ptr(), labels.data_ptr(), losses.data_ptr(), lse.data_ptr(),
+                                     rows, cols, logits.stride(0), float(smoothing), int(total_classes),
+                                     _xent_dtype(logits), _stream())
+    _check(code, 'bp_xentropy_fwd')
+    return losses, lse
+
+
+def xentropy_bwd(grad_losses, logits, lse, labels, smoothing=0.0, inplace=False, total_classes=-1):
+    """d loss / d logits in the logits' dtype; `inplace` overwrites `logits` (upstream's inplace_backward,
+    cross_entropy.py:103-105)."""
+    _require_cuda(grad_losses, logits, lse, labels)
+    rows, cols = logits.shape
+    grad = logits if inplace else torch.empty_like(logits)
+    g = grad_losses.to(torch.float32).contiguous()
+    labels = labels.to(torch.int64).contiguous()
+    with torch.cuda.device(logits.device):
+        code = lib().bp_xentropy_bwd(g.data_ptr(), logits.data_ptr(), lse.data_ptr(), labels.data_ptr(),
+                                     grad.data_ptr(), rows, cols, logits.stride(0), grad.stride(0),
+                                     float(smoothing), int(total_classes), _xent_dtype(logits), _stream())
+    _check(code, 'bp_xentropy_bwd')
+    return grad
 
 
 class GraphedForward:

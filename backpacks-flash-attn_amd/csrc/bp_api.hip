@@ -323,4 +323,45 @@ int bp_add_layer_norm(const void *x0, const void *x1, const void *gamma, const v
     return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
 }
 
+static int xent_common(int64_t rows, int cols, int64_t row_stride, float smoothing, int dtype) {
+    if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16 && dtype != BP_DTYPE_F32) return BP_ERR_DTYPE;
+    if (rows <= 0 || rows > 0x7fffffffLL || cols <= 0 || row_stride < cols) return BP_ERR_SHAPE;
+    if (!(smoothing >= 0.f && smoothing < 1.f)) return BP_ERR_SCALE;
+    return BP_OK;
+}
+
+int bp_xentropy_fwd(const void *logits, const int64_t *labels, float *losses, float *lse,
+                    int64_t rows, int cols, int64_t row_stride, float smoothing, int total_classes,
+                    int dtype, bp_stream_t stream) {
+    const int rc = xent_common(rows, cols, row_stride, smoothing, dtype);
+    if (rc != BP_OK) return rc;
+    if (logits == nullptr || labels == nullptr || losses == nullptr || lse == nullptr) return BP_ERR_SHAPE;
+    bp::XentParams p{};
+    p.logits = logits; p.labels = labels; p.losses = losses; p.lse = lse;
+    p.rows = rows; p.cols = cols; p.row_stride = row_stride;
+    p.total_classes = total_classes > 0 ? total_classes : cols;
+    p.smoothing = smoothing;
+    hipError_t e = bp::launch_xentropy_fwd(p, dtype, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
+}
+
+int bp_xentropy_bwd(const float *grad_losses, const void *logits, const float *lse, const int64_t *labels,
+                    void *grad_logits, int64_t rows, int cols, int64_t row_stride, int64_t grad_row_stride,
+                    float smoothing, int total_classes, int dtype, bp_stream_t stream) {
+    const int rc = xent_common(rows, cols, row_stride, smoothing, dtype);
+    if (rc != BP_OK) return rc;
+    if (grad_row_stride < cols) return BP_ERR_SHAPE;
+    if (grad_losses == nullptr || logits == nullptr || lse == nullptr || labels == nullptr ||
+        grad_logits == nullptr)
+        return BP_ERR_SHAPE;
+    bp::XentParams p{};
+    p.logits = logits; p.labels = labels; p.lse = const_cast<float *>(lse); p.grad_losses = grad_losses;
+    p.grad_logits = grad_logits;
+    p.rows = rows; p.cols = cols; p.row_stride = row_stride; p.grad_row_stride = grad_row_stride;
+    p.total_classes = total_classes > 0 ? total_classes : cols;
+    p.smoothing = smoothing;
+    hipError_t e = bp::launch_xentropy_bwd(p, dtype, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
+}
+
 }  // extern "C"

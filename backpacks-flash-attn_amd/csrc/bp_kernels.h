@@ -70,6 +70,20 @@ struct MixParams {
     float scale_log2e;
 };
 
+struct XentParams {
+    const void *logits;        // (rows, cols), row stride in elements, last stride 1
+    const int64_t *labels;     // (rows)
+    float *losses, *lse;       // (rows) fp32                                   [forward out / backward in: lse]
+    const float *grad_losses;  // (rows) fp32                                   [backward]
+    void *grad_logits;         // (rows, cols) logits' dtype, may alias logits   [backward]
+    int64_t rows, row_stride, grad_row_stride;
+    int cols, total_classes;
+    float smoothing;
+};
+
+hipError_t launch_xentropy_fwd(const XentParams &p, int dtype, hipStream_t stream);
+hipError_t launch_xentropy_bwd(const XentParams &p, int dtype, hipStream_t stream);
+
 struct LnParams {
     const void *x0;           // (rows, cols) 16-bit
     const void *x1;           // (rows, cols) residual in, 16-bit or fp32, may be NULL

@@ -26,6 +26,7 @@ extern "C" {
 /* element type of q/k/v/out/content tensors */
 #define BP_DTYPE_F16 0
 #define BP_DTYPE_BF16 1
+#define BP_DTYPE_F32 2   /* accepted by the cross-entropy entry points only */
 
 #define BP_OK 0
 #define BP_ERR_DTYPE -1       /* dtype is not BP_DTYPE_F16 / BP_DTYPE_BF16         (fmha_api.cpp:215-219) */
@@ -202,6 +203,29 @@ int bp_flash_bwd(const void *dout, const void *q, const void *k, const void *v, 
 int bp_add_layer_norm(const void *x0, const void *x1, const void *gamma, const void *beta, void *z,
                       void *x_out, int64_t rows, int cols, float epsilon, int dtype, int x1_is_f32,
                       int xout_is_f32, int w_is_f32, bp_stream_t stream);
+
+/*
+ * bp_xentropy_fwd / bp_xentropy_bwd -- fused softmax cross-entropy over vocabulary-sized rows.
+ * Replace xentropy_cuda_lib.forward(logits, labels, smoothing[, total_classes]) -> (losses, lse) and
+ * xentropy_cuda_lib.backward(grad_loss, logits, lse, labels, smoothing, inplace, total_classes)
+ * (flash_attn/losses/cross_entropy.py:37,54,103-105):
+ *   lse_i  = log sum_j exp(x_ij)
+ *   loss_i = (1 - s)(lse_i - x_i[y_i]) + s (lse_i - sum_j x_ij / total_classes)
+ *   dx_ij  = g_i (exp(x_ij - lse_i) - (1 - s)[j == y_i] - s / total_classes)
+ * A label outside [0, cols) has no x_i[y_i] term (shifted labels of the vocabulary-parallel caller,
+ * cross_entropy.py:41-63); rows with the ignore index are zeroed by the caller (:39,:101).
+ *   logits       (rows, cols) fp16 / bf16 / fp32 (dtype 0 / 1 / 2), row stride in elements, last stride 1
+ *   labels       (rows) int64
+ *   losses, lse  (rows) fp32
+ *   grad_logits  (rows, cols) in the logits' dtype; MAY BE the logits buffer itself (inplace_backward)
+ *   total_classes  <= 0: cols
+ */
+int bp_xentropy_fwd(const void *logits, const int64_t *labels, float *losses, float *lse,
+                    int64_t rows, int cols, int64_t row_stride, float smoothing, int total_classes,
+                    int dtype, bp_stream_t stream);
+int bp_xentropy_bwd(const float *grad_losses, const void *logits, const float *lse, const int64_t *labels,
+                    void *grad_logits, int64_t rows, int cols, int64_t row_stride, int64_t grad_row_stride,
+                    float smoothing, int total_classes, int dtype, bp_stream_t stream);
 
 #ifdef __cplusplus
 }

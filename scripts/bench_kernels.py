@@ -90,6 +90,16 @@ def main():
         by = (4 * S * d + 2 * K * S * S) * Ba
         res.append(dict(kernel='attn_probs(alpha)', batch=Ba, ms=ms, tflops=2 * pairs * d * Ba / ms / 1e9,
                         gbps=by / ms / 1e6))
+    if 'xent' in which:
+        rows, V = min(B * S, 32768), 50264
+        x = torch.randn(rows, V, device=dev).to(dt)
+        y = torch.randint(0, V, (rows,), device=dev)
+        ms = timeit(lambda: bp_hip.xentropy_fwd(x, y), a.iters)
+        res.append(dict(kernel='xentropy_fwd', rows=rows, ms=ms, tflops=0.0, gbps=rows * V * 2 / ms / 1e6))
+        losses, lse = bp_hip.xentropy_fwd(x, y)
+        g = torch.ones(rows, device=dev)
+        ms = timeit(lambda: bp_hip.xentropy_bwd(g, x, lse, y, inplace=False), a.iters)
+        res.append(dict(kernel='xentropy_bwd', rows=rows, ms=ms, tflops=0.0, gbps=rows * V * 4 / ms / 1e6))
     for r in res:
         r.update(batch=r.get('batch', B), seq=S, dtype=a.dtype)
         print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}), flush=True)

@@ -417,3 +417,70 @@ def test_sense_mix_seq4096_fp16_rows():
     alpha = torch.softmax(scores.masked_fill(mask[None], float('-inf')), -1)         # (k, rows, S)
     want = torch.einsum('lts,sld->td', alpha, c[0].float())
     assert (out[0, rows].float().cpu() - want).abs().max().item() < 2e-2
+
+
+# ---------------------------------------------------------------------------------------------
+# Fused cross-entropy (next row 4): criterion of the reference's own test, tests/losses/test_cross_entropy.py
+# (rtol/atol 1e-5/1e-6 fp32, 1e-3/1e-4 16-bit against torch CrossEntropyLoss on fp32 logits)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('dtype', [torch.float16, torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('inplace_backward', [False, True])
+@pytest.mark.parametrize('smoothing', [0.0, 0.9])
+@pytest.mark.parametrize('vocab_size', [50257, 50264, 1000, 7])
+def test_cross_entropy_loss(vocab_size, smoothing, inplace_backward, dtype):
+    from flash_attn.losses.cross_entropy import CrossEntropyLossApex
+    rtol, atol = (1e-5, 1e-6) if dtype == torch.float32 else (1e-3, 1e-4)
+    if dtype == torch.bfloat16:
+        rtol, atol = 8e-3, 1e-4            # bf16 has 3 fewer mantissa bits than the reference's fp16 case
+    torch.manual_seed(0)
+    rows = 256
+    x_pt = torch.randn(rows, vocab_size, device=DEV, dtype=dtype, requires_grad=True)
+    x = x_pt.detach().clone().requires_grad_()
+    y = torch.randint(0, vocab_size, (rows,), dtype=torch.long, device=DEV)
+    y[torch.randperm(rows)[:10]] = -100
+    out = CrossEntropyLossApex(label_smoothing=smoothing, inplace_backward=inplace_backward)(x, y)
+    out_pt = torch.nn.CrossEntropyLoss(label_smoothing=smoothing)(x_pt.float(), y)
+    assert torch.allclose(out, out_pt, rtol=rtol, atol=atol), (out.item(), out_pt.item())
+    g = torch.randn_like(out)
+    out_pt.backward(g)
+    out.backward(g)
+    assert torch.allclose(x.grad, x_pt.grad, rtol=rtol, atol=atol)
+    # per-row values against the CPU oracle, unreduced
+    losses, lse = _bp().xentropy_fwd(x_pt.detach(), y, smoothing)
+    want_l, want_lse = R.softmax_cross_entropy(x_pt.detach().cpu(), y.cpu(), smoothing)
+    assert (lse.cpu() - want_lse).abs().max().item() < 2e-4
+    assert (losses.masked_fill(y == -100, 0).cpu() - want_l).abs().max().item() < 2e-3
+
+
+def test_cross_entropy_strided_rows_and_shard_labels():
+    """Row-strided logits (a column slice of a wider buffer: unaligned row starts) and labels outside the
+    local vocabulary slice (vocabulary-parallel contract, cross_entropy.py:41-63)."""
+    bp = _bp()
+    torch.manual_seed(1)
+    wide = torch.randn(64, 3001, device=DEV).bfloat16()
+    x = wide[:, 3:2004]                                    # 2001 columns, row stride 3001, odd offset
+    y = torch.randint(-500, 2500, (64,), device=DEV)
+    losses, lse = bp.xentropy_fwd(x, y, 0.1, total_classes=6000)
+    want_l, want_lse = R.softmax_cross_entropy(x.cpu(), y.cpu(), 0.1, total_classes=6000)
+    assert (lse.cpu() - want_lse).abs().max().item() < 2e-4
+    assert (losses.cpu() - want_l).abs().max().item() < 2e-3
+    g = torch.randn(64, device=DEV)
+    dx = bp.xentropy_bwd(g, x, lse, y, 0.1, total_classes=6000)
+    want = R.softmax_cross_entropy_grad(g.cpu(), x.cpu(), y.cpu(), 0.1, ignored_index=-100, total_classes=6000)
+    assert (dx.float().cpu() - want).abs().max().item() < 2e-2 * g.abs().max().item()
+
+
+def test_chunked_lm_loss_matches_full_logits():
+    from src.models.backpack import BackpackConfig, BackpackLMHeadModel
+    from src.utils.perplexity import lm_loss_chunked
+    cfg = BackpackConfig(n_embd=128, n_head=2, n_layer=2, num_content_vectors=4, vocab_size=1000, n_positions=64,
+                         scale_attn_by_inverse_layer_idx=True, resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0,
+                         use_flash_attn=True, pad_vocab_size_multiple=8)
+    torch.manual_seed(2)
+    model = BackpackLMHeadModel(cfg).eval().to(DEV, torch.bfloat16)
+    ids = torch.randint(0, 1000, (6, 64), device=DEV)
+    loss, n = lm_loss_chunked(model, ids, chunk_tokens=100)          # 384 rows in ragged chunks of 100
+    with torch.no_grad():
+        logits = model(ids).logits.float()
+    want = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), ids[:, 1:].reshape(-1))
+    assert n == 6 * 63 and abs(loss.item() - want.item()) < 2e-3

@@ -108,3 +108,21 @@ def test_intervention_oracle_against_reference_golden():
     senses = {int(w): torch.from_numpy(g['sense/%d' % w]) for w in g['sense_words']}
     got = R.replaced_word_logits(sd, cfg, ids, senses)
     assert (got - torch.from_numpy(g['replaced'])).abs().max().item() < 5e-5
+
+
+def test_cross_entropy_oracle_against_the_reference_tests_own_oracle():
+    """oracle softmax_cross_entropy (+ grad) == torch.nn.CrossEntropyLoss(label_smoothing) on fp32 logits, which
+    is what the reference's test pins its kernel to (tests/losses/test_cross_entropy.py:31-41)."""
+    torch.manual_seed(0)
+    x = torch.randn(64, 1000, requires_grad=True)
+    y = torch.randint(0, 1000, (64,))
+    y[::7] = -100
+    for s in (0.0, 0.9):
+        losses, lse = R.softmax_cross_entropy(x.detach(), y, s)
+        want = torch.nn.functional.cross_entropy(x, y, label_smoothing=s, reduction='none')
+        assert (losses - want.detach()).abs().max().item() < 2e-5
+        assert (lse - torch.logsumexp(x.detach(), 1)).abs().max().item() < 1e-6
+        g = torch.randn(64)
+        (gx,) = torch.autograd.grad(want, x, g)
+        got = R.softmax_cross_entropy_grad(g, x.detach(), y, s)
+        assert (got - gx).abs().max().item() < 1e-6
