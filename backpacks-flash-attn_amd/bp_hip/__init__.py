@@ -31,6 +31,7 @@ SIGNATURES = {
     'bp_sense_mix': (_i32, [_ptr] * 4 + [_i32] * 6 + [_i64] * 9 + [_f32, _i32, _ptr]),
     'bp_sense_mix_weighted': (_i32, [_ptr] * 5 + [_i32] * 6 + [_i64] * 11 + [_f32, _i32, _ptr]),
     'bp_add_layer_norm': (_i32, [_ptr] * 6 + [_i64, _i32, _f32] + [_i32] * 4 + [_ptr]),
+    'bp_add_layer_norm_bwd': (_i32, [_ptr] * 9 + [_i64, _i32, _f32, _i32, _i32, _i32, _ptr]),
     'bp_xentropy_fwd': (_i32, [_ptr] * 4 + [_i64, _i32, _i64, _f32, _i32, _i32, _ptr]),
     'bp_xentropy_bwd': (_i32, [_ptr] * 5 + [_i64, _i32, _i64, _i64, _f32, _i32, _i32, _ptr]),
 }
@@ -328,6 +329,39 @@ def add_layer_norm(x0, x1, weight, bias, eps, residual_dtype=None, return_residu
             int(weight.dtype == torch.float32), _stream())
     _check(code, 'bp_add_layer_norm')
     return (z, xo) if return_residual else z
+
+
+LN_BWD_WS_ROWS = 1024
+
+
+def add_layer_norm_bwd_supported(x0_dtype, cols):
+    return x0_dtype in (torch.float16, torch.bfloat16) and cols % 4 == 0 and cols <= 2048
+
+
+def add_layer_norm_bwd(dz, dx_in, x, weight, eps, want_dx1):
+    """Backward of add_layer_norm: (dx0 in dz's dtype, dx1 in x's dtype or None, dweight, dbias).
+    dz (..., cols) 16-bit; dx_in gradient of the residual output (x's dtype) or None; x the summed stream
+    the forward normalised (fp32 or dz's dtype).  Replaces dropout_add_ln_bwd with dropout_p = 0
+    (flash_attn/ops/layer_norm.py:47-76)."""
+    _require_cuda(dz, dx_in, x, weight)
+    cols = dz.shape[-1]
+    dzc, xc = dz.contiguous(), x.contiguous()
+    dxc = dx_in.contiguous() if dx_in is not None else None
+    if xc.dtype not in (torch.float32, dzc.dtype) or (dxc is not None and dxc.dtype != xc.dtype):
+        raise RuntimeError('bp_hip.add_layer_norm_bwd: x / dx_in must be fp32 or dz\'s dtype, and agree')
+    rows = dzc.numel() // cols
+    dx0 = torch.empty_like(dzc)
+    dx1 = torch.empty_like(xc) if want_dx1 else None
+    dw, db = torch.empty_like(weight), torch.empty_like(weight)
+    ws = torch.empty((2, LN_BWD_WS_ROWS, cols), dtype=torch.float32, device=dz.device)
+    with torch.cuda.device(dz.device):
+        code = lib().bp_add_layer_norm_bwd(
+            dzc.data_ptr(), dxc.data_ptr() if dxc is not None else None, xc.data_ptr(), weight.data_ptr(),
+            dx0.data_ptr(), dx1.data_ptr() if dx1 is not None else None, dw.data_ptr(), db.data_ptr(),
+            ws.data_ptr(), rows, cols, float(eps), _dtype_code(dzc), int(xc.dtype == torch.float32),
+            int(weight.dtype == torch.float32), _stream())
+    _check(code, 'bp_add_layer_norm_bwd')
+    return dx0, dx1, dw, db
 
 
 def _xent_dtype(t):

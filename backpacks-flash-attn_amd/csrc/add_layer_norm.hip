@@ -134,4 +134,187 @@ hipError_t launch_add_layer_norm(const LnParams &p, int dtype, hipStream_t strea
     return dtype == 1 ? launch_et<BF16>(p, stream) : launch_et<F16>(p, stream);
 }
 
+// =====================================================================================================
+// Backward (reference: DropoutAddLayerNormFn.backward, flash_attn/ops/layer_norm.py:131-152;
+// csrc/layer_norm/ln_bwd_kernels.cuh, eval path: no dropout / rowscale / colscale)
+//
+//     xhat = (x - mu) rs            dy = dz * gamma
+//     dx   = rs (dy - mean(dy) - xhat mean(dy xhat)) + dx_in         (dx0 = dx1 = dx: x = x0 + x1)
+//     dgamma = sum_rows dz xhat     dbeta = sum_rows dz
+//
+// mu and rs are recomputed from the saved x (read anyway), so the forward stores no statistics.  One wave
+// per row, each wave strides over rows and keeps its lanes' columns of dgamma / dbeta in registers; the
+// four waves of a workgroup fold theirs through LDS into one partial row of the workspace and a second
+// small kernel sums the partial rows (deterministic: no atomics).
+// =====================================================================================================
+BP_DEV void wave_sum2(float &a, float &b) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        a += __shfl_xor(a, m);
+        b += __shfl_xor(b, m);
+    }
+}
+
+template <class ET, int CH, bool RES_F32, bool W_F32>
+__global__ __launch_bounds__(256) void add_layer_norm_bwd_kernel(const LnBwdParams p) {
+    __shared__ float fold[2][CH * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv_n = 1.f / (float)p.cols;
+
+    float g[CH][4], dg[CH][4], db[CH][4];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int col = (c * 64 + lane) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { g[c][i] = 0.f; dg[c][i] = 0.f; db[c][i] = 0.f; }
+        if (col < p.cols) load4<ET, W_F32>(p.gamma, col, g[c]);
+    }
+
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < p.rows; row += (int64_t)p.n_wg * 4) {
+        const int64_t base = row * p.cols;
+        float x[CH][4], dy[CH][4];
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int col = (c * 64 + lane) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { x[c][i] = 0.f; dy[c][i] = 0.f; }
+            if (col < p.cols) {
+                load4<ET, RES_F32>(p.x, base + col, x[c]);
+                load4<ET, false>(p.dz, base + col, dy[c]);      // dz for now
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sum += x[c][i];
+            }
+        }
+        const float mu = wave_sum(sum) * inv_n;
+        float m2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int col = (c * 64 + lane) * 4;
+            if (col < p.cols) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float d = x[c][i] - mu;
+                    m2 += d * d;
+                }
+            }
+        }
+        const float rs = rsqrtf(wave_sum(m2) * inv_n + p.eps);
+        float s1 = 0.f, s2 = 0.f;   // sum dy, sum dy * xhat
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int col = (c * 64 + lane) * 4;
+            if (col < p.cols) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float xhat = (x[c][i] - mu) * rs;
+                    const float dz = dy[c][i];
+                    dg[c][i] += dz * xhat;
+                    db[c][i] += dz;
+                    const float d = dz * g[c][i];
+                    s1 += d;
+                    s2 += d * xhat;
+                    x[c][i] = xhat;
+                    dy[c][i] = d;
+                }
+            }
+        }
+        wave_sum2(s1, s2);
+        const float c1 = s2 * inv_n, c2 = s1 * inv_n;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int col = (c * 64 + lane) * 4;
+            if (col < p.cols) {
+                float dx[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dx[i] = rs * (dy[c][i] - c2 - x[c][i] * c1);
+                if (p.dx_in != nullptr) {
+                    float r[4];
+                    load4<ET, RES_F32>(p.dx_in, base + col, r);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dx[i] += r[i];
+                }
+                store4<ET, false>(p.dx0, base + col, dx);
+                if (p.dx1 != nullptr) store4<ET, RES_F32>(p.dx1, base + col, dx);
+            }
+        }
+    }
+
+    // fold the four waves' column sums (wave after wave: fixed order) and publish one partial row
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int idx = (c * 64 + lane) * 4 + i;
+                    fold[0][idx] = (w == 0 ? 0.f : fold[0][idx]) + dg[c][i];
+                    fold[1][idx] = (w == 0 ? 0.f : fold[1][idx]) + db[c][i];
+                }
+        }
+        __syncthreads();
+    }
+    for (int col = threadIdx.x; col < p.cols; col += 256) {
+        p.ws[(int64_t)blockIdx.x * p.cols + col] = fold[0][col];
+        p.ws[((int64_t)kLnBwdMaxWg + blockIdx.x) * p.cols + col] = fold[1][col];
+    }
+}
+
+// Sum of the partial rows: 64 columns per workgroup, 16 row slices per column (1024 threads) so that the
+// serial part is n_wg / 16 coalesced loads per thread, then a fixed-order fold through LDS.
+template <class ET, bool W_F32>
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const LnBwdParams p) {
+    __shared__ float part[2][16][64];
+    const int c = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + c;
+    float a = 0.f, b = 0.f;
+    if (col < p.cols) {
+        for (int r = slice; r < p.n_wg; r += 16) {
+            a += p.ws[(int64_t)r * p.cols + col];
+            b += p.ws[((int64_t)kLnBwdMaxWg + r) * p.cols + col];
+        }
+    }
+    part[0][slice][c] = a;
+    part[1][slice][c] = b;
+    __syncthreads();
+    if (slice != 0 || col >= p.cols) return;
+    for (int s = 1; s < 16; ++s) {
+        a += part[0][s][c];
+        b += part[1][s][c];
+    }
+    if (W_F32) {
+        static_cast<float *>(p.dgamma)[col] = a;
+        static_cast<float *>(p.dbeta)[col] = b;
+    } else {
+        static_cast<uint16_t *>(p.dgamma)[col] = Elem<ET>::from_float(a);
+        static_cast<uint16_t *>(p.dbeta)[col] = Elem<ET>::from_float(b);
+    }
+}
+
+template <class ET, bool RES_F32, bool W_F32>
+static hipError_t launch_bwd_flags(const LnBwdParams &p, hipStream_t stream) {
+    const int ch = (p.cols + 255) / 256;
+    dim3 g((unsigned)p.n_wg), t(256);
+#define BP_LNB_CASE(N) \
+    if (ch <= N) { hipLaunchKernelGGL((add_layer_norm_bwd_kernel<ET, N, RES_F32, W_F32>), g, t, 0, stream, p); } else
+    BP_LNB_CASE(1) BP_LNB_CASE(2) BP_LNB_CASE(3) BP_LNB_CASE(4) BP_LNB_CASE(6) BP_LNB_CASE(8)
+    { return hipErrorNotSupported; }
+#undef BP_LNB_CASE
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((ln_bwd_reduce_kernel<ET, W_F32>), dim3((p.cols + 63) / 64), dim3(1024), 0, stream, p);
+    return hipGetLastError();
+}
+
+template <class ET>
+static hipError_t launch_bwd_et(const LnBwdParams &p, hipStream_t stream) {
+    if (p.res_f32) return p.w_f32 ? launch_bwd_flags<ET, true, true>(p, stream) : launch_bwd_flags<ET, true, false>(p, stream);
+    return p.w_f32 ? launch_bwd_flags<ET, false, true>(p, stream) : launch_bwd_flags<ET, false, false>(p, stream);
+}
+
+// cols % 4 == 0 and <= 2048 (the model widths 384 / 640 / 768 and up); larger rows: hipErrorNotSupported
+hipError_t launch_add_layer_norm_bwd(const LnBwdParams &p, int dtype, hipStream_t stream) {
+    return dtype == 1 ? launch_bwd_et<BF16>(p, stream) : launch_bwd_et<F16>(p, stream);
+}
+
 }  // namespace bp

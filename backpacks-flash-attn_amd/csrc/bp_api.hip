@@ -323,6 +323,28 @@ int bp_add_layer_norm(const void *x0, const void *x1, const void *gamma, const v
     return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
 }
 
+int bp_add_layer_norm_bwd(const void *dz, const void *dx_in, const void *x, const void *gamma,
+                          void *dx0, void *dx1, void *dgamma, void *dbeta, float *ws,
+                          int64_t rows, int cols, float epsilon, int dtype, int res_is_f32, int w_is_f32,
+                          bp_stream_t stream) {
+    static_assert(BP_LN_BWD_WS_ROWS == bp::kLnBwdMaxWg, "workspace rows");
+    if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
+    if (rows <= 0 || cols <= 0 || cols % 4 != 0 || cols > 2048) return BP_ERR_SHAPE;
+    if (!dz || !x || !gamma || !dx0 || !dgamma || !dbeta || !ws) return BP_ERR_SHAPE;
+    const void *ptrs[] = {dz, dx_in, x, gamma, dx0, dx1, dgamma, dbeta, ws};
+    for (const void *ptr : ptrs) if (ptr != nullptr && !aligned16(ptr)) return BP_ERR_SHAPE;
+    if (!(isfinite(epsilon) && epsilon >= 0.f)) return BP_ERR_SCALE;
+    bp::LnBwdParams p{};
+    p.dz = dz; p.dx_in = dx_in; p.x = x; p.gamma = gamma; p.dx0 = dx0; p.dx1 = dx1;
+    p.dgamma = dgamma; p.dbeta = dbeta; p.ws = ws;
+    p.rows = rows; p.cols = cols; p.eps = epsilon;
+    p.n_wg = (int)((rows + 3) / 4 < bp::kLnBwdMaxWg ? (rows + 3) / 4 : bp::kLnBwdMaxWg);
+    p.res_f32 = res_is_f32 ? 1 : 0; p.w_f32 = w_is_f32 ? 1 : 0;
+    hipError_t e = bp::launch_add_layer_norm_bwd(p, dtype, static_cast<hipStream_t>(stream));
+    if (e == hipErrorNotSupported) return BP_ERR_SHAPE;
+    return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
+}
+
 static int xent_common(int64_t rows, int cols, int64_t row_stride, float smoothing, int dtype) {
     if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16 && dtype != BP_DTYPE_F32) return BP_ERR_DTYPE;
     if (rows <= 0 || rows > 0x7fffffffLL || cols <= 0 || row_stride < cols) return BP_ERR_SHAPE;

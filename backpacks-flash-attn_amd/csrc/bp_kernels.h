@@ -97,6 +97,23 @@ struct LnParams {
 };
 
 hipError_t launch_add_layer_norm(const LnParams &p, int dtype, hipStream_t stream);
+
+constexpr int kLnBwdMaxWg = 1024;   // row-parallel workgroups of the backward = rows of its partial-sum workspace
+struct LnBwdParams {
+    const void *dz;           // (rows, cols) 16-bit: gradient of the normalised output
+    const void *dx_in;        // (rows, cols) residual dtype: gradient of the residual output (prenorm), may be NULL
+    const void *x;            // (rows, cols) residual dtype: the summed stream x0 + x1 the forward normalised
+    const void *gamma;        // (cols) 16-bit or fp32
+    void *dx0;                // (rows, cols) 16-bit
+    void *dx1;                // (rows, cols) residual dtype, may be NULL (same values as dx0)
+    void *dgamma, *dbeta;     // (cols) gamma's dtype
+    float *ws;                // (2, kLnBwdMaxWg, cols) fp32 partial sums
+    int64_t rows;
+    int cols, n_wg;
+    int res_f32, w_f32;
+    float eps;
+};
+hipError_t launch_add_layer_norm_bwd(const LnBwdParams &p, int dtype, hipStream_t stream);
 hipError_t launch_flash_fwd(const FlashParams &p, int dtype, bool vec, hipStream_t stream);
 // LDS-DMA ring version; needs 16-byte friendly shapes (vec)
 hipError_t launch_flash_fwd_dma(const FlashParams &p, int dtype, hipStream_t stream);

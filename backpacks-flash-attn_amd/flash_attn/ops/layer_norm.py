@@ -2,9 +2,9 @@
 flash_attn/ops/layer_norm.py (`dropout_add_layer_norm` :207-217, `layer_norm` :203-204,
 `DropoutAddLayerNorm` :232-252) on the HIP kernel bp_add_layer_norm.
 
-Forward/eval path only: dropout_p must be 0 and rowscale / layerscale (DropPath, LayerScale) are not
-supported -- the Backpack / GPT-2 configs use neither in eval.  Backward recomputes with eager ops
-(fused backward kernels are a "next" row)."""
+dropout_p must be 0 and rowscale / layerscale (DropPath, LayerScale) are not supported -- the Backpack /
+GPT-2 configs use neither in eval.  Backward is the HIP kernel bp_add_layer_norm_bwd for rows up to 2048
+columns (statistics recomputed from the saved summed stream); wider rows differentiate the eager expression."""
 import torch
 import torch.nn.functional as F
 from torch.nn import init
@@ -22,29 +22,32 @@ class DropoutAddLayerNormFn(torch.autograd.Function):
             z, x = bp_hip.add_layer_norm(x0, x1, gamma, beta, epsilon, residual_dtype=residual_dtype)
         else:
             z, x = bp_hip.add_layer_norm(x0, None, gamma, beta, epsilon, return_residual=False), None
-        ctx.save_for_backward(x0, x1, gamma, beta)
+        # backward needs the SUM the LayerNorm saw (statistics are recomputed from it), not x0 and x1
+        ctx.save_for_backward(x if x is not None else x0, gamma, beta)
         ctx.eps, ctx.prenorm, ctx.residual_dtype = epsilon, prenorm, residual_dtype
+        ctx.x0_dtype, ctx.has_x1 = x0.dtype, x1 is not None
         return (z, x) if prenorm else z
 
     @staticmethod
     def backward(ctx, dz, *args):
-        x0, x1, gamma, beta = ctx.saved_tensors
-        dx = args[0] if args else None
-        with torch.enable_grad():
-            a = x0.detach().requires_grad_()
-            b = x1.detach().requires_grad_() if x1 is not None else None
+        xsum, gamma, beta = ctx.saved_tensors
+        dx = args[0] if (ctx.prenorm and args) else None
+        if bp_hip.add_layer_norm_bwd_supported(ctx.x0_dtype, xsum.shape[-1]):
+            if dx is not None and dx.dtype != xsum.dtype:
+                dx = dx.to(xsum.dtype)
+            dx0, dx1, dg, dbt = bp_hip.add_layer_norm_bwd(dz, dx, xsum, gamma, ctx.eps, want_dx1=ctx.has_x1)
+            return dx0.view_as(dz), (dx1.view_as(xsum) if ctx.has_x1 else None), dg, dbt, None, None, None
+        with torch.enable_grad():   # wide rows: differentiate the eager expression
+            a = xsum.detach().float().requires_grad_()
             g, bt = gamma.detach().requires_grad_(), beta.detach().requires_grad_()
-            x = a.float() + (b.float() if b is not None else 0.0)
-            z = F.layer_norm(x, (x.shape[-1],), g.float(), bt.float(), ctx.eps).to(x0.dtype)
+            z = F.layer_norm(a, (a.shape[-1],), g.float(), bt.float(), ctx.eps).to(ctx.x0_dtype)
             outs, grads = [z], [dz]
-            if ctx.prenorm and dx is not None:
-                outs.append(x.to(ctx.residual_dtype))
+            if dx is not None:
+                outs.append(a.to(ctx.residual_dtype))
                 grads.append(dx)
-            inputs = [a, g, bt] + ([b] if b is not None else [])
-            res = torch.autograd.grad(outs, inputs, grads)
-        da, dg, dbt = res[0], res[1], res[2]
-        db = res[3] if b is not None else None
-        return da, db, dg, dbt, None, None, None
+            da, dg, dbt = torch.autograd.grad(outs, [a, g, bt], grads)
+        return (da.to(ctx.x0_dtype), (da.to(ctx.residual_dtype) if ctx.has_x1 else None), dg, dbt,
+                None, None, None)
 
 
 def dropout_add_layer_norm(x0, x1, weight, bias, dropout_p, epsilon, rowscale=None, layerscale=None,

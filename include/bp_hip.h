@@ -205,6 +205,23 @@ int bp_add_layer_norm(const void *x0, const void *x1, const void *gamma, const v
                       int xout_is_f32, int w_is_f32, bp_stream_t stream);
 
 /*
+ * bp_add_layer_norm_bwd -- backward of bp_add_layer_norm (eval-path subset of the reference's
+ * dropout_add_ln_bwd, csrc/layer_norm/ln_api.cpp:256-408; Python side flash_attn/ops/layer_norm.py:131-152):
+ *   dx = rs (dz*gamma - mean(dz*gamma) - xhat mean(dz*gamma*xhat)) + dx_in ;  dgamma = sum dz*xhat ; dbeta = sum dz
+ * with mean / rstd recomputed from `x`, the summed stream the forward normalised (its x_out; x0 itself when
+ * the forward had no residual).  dx0 and dx1 receive the same values in their own dtypes.
+ *   dz, dx0      (rows, cols) 16-bit           dx_in, x, dx1  (rows, cols) residual dtype (dx_in / dx1 may be NULL)
+ *   gamma, dgamma, dbeta  (cols) fp32 or 16-bit (w_is_f32)
+ *   ws           fp32 workspace, 2 * BP_LN_BWD_WS_ROWS * cols elements
+ * cols % 4 == 0 and <= 2048 (BP_ERR_SHAPE otherwise: callers differentiate the eager expression instead).
+ */
+#define BP_LN_BWD_WS_ROWS 1024
+int bp_add_layer_norm_bwd(const void *dz, const void *dx_in, const void *x, const void *gamma,
+                          void *dx0, void *dx1, void *dgamma, void *dbeta, float *ws,
+                          int64_t rows, int cols, float epsilon, int dtype, int res_is_f32, int w_is_f32,
+                          bp_stream_t stream);
+
+/*
  * bp_xentropy_fwd / bp_xentropy_bwd -- fused softmax cross-entropy over vocabulary-sized rows.
  * Replace xentropy_cuda_lib.forward(logits, labels, smoothing[, total_classes]) -> (losses, lse) and
  * xentropy_cuda_lib.backward(grad_loss, logits, lse, labels, smoothing, inplace, total_classes)

@@ -90,6 +90,15 @@ def main():
         by = (4 * S * d + 2 * K * S * S) * Ba
         res.append(dict(kernel='attn_probs(alpha)', batch=Ba, ms=ms, tflops=2 * pairs * d * Ba / ms / 1e9,
                         gbps=by / ms / 1e6))
+    if 'lnbwd' in which:
+        rows, cols = B * S, d
+        x = torch.randn(rows, cols, device=dev)
+        dz = torch.randn(rows, cols, device=dev).to(dt)
+        dxr = torch.randn(rows, cols, device=dev)
+        w = torch.ones(cols, device=dev)
+        ms = timeit(lambda: bp_hip.add_layer_norm_bwd(dz, dxr, x, w, 1e-5, want_dx1=True), a.iters)
+        # reads dz (2) + dx_in (4) + x (4), writes dx0 (2) + dx1 (4) bytes per element
+        res.append(dict(kernel='add_layer_norm_bwd', ms=ms, tflops=0.0, gbps=rows * cols * 16 / ms / 1e6))
     if 'xent' in which:
         rows, V = min(B * S, 32768), 50264
         x = torch.randn(rows, V, device=dev).to(dt)

@@ -484,3 +484,80 @@ def test_chunked_lm_loss_matches_full_logits():
         logits = model(ids).logits.float()
     want = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), ids[:, 1:].reshape(-1))
     assert n == 6 * 63 and abs(loss.item() - want.item()) < 2e-3
+
+
+# ---------------------------------------------------------------------------------------------
+# Fused add + LayerNorm BACKWARD (next row 3).  Criterion of tests/ops/test_dropout_layer_norm.py:236-250:
+# fp32 autograd of the fp32 expression is truth, eager same-dtype autograd the yardstick (x4 + 1e-4 for
+# activations' grads, x2 + 2e-4 for weight / bias).
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('cols', [768, 384, 640, 1024, 2048, 2560])
+@pytest.mark.parametrize('mode', ['prenorm_fp32res', 'prenorm_same_dtype', 'postnorm_residual', 'no_residual',
+                                  'no_residual_fp32_stream'])
+def test_add_layer_norm_backward(cols, dtype, mode):
+    from flash_attn.ops.layer_norm import dropout_add_layer_norm
+    torch.manual_seed(7)
+    rows = 4 * 331 + 3                       # not a multiple of the 4 rows per workgroup
+    prenorm = mode.startswith('prenorm')
+    has_x1 = mode in ('prenorm_fp32res', 'prenorm_same_dtype', 'postnorm_residual')
+    res_dtype = torch.float32 if mode in ('prenorm_fp32res', 'postnorm_residual') else dtype
+    w_dtype = torch.float32 if mode != 'prenorm_same_dtype' else dtype
+    x0 = torch.randn(rows, cols).to(dtype)
+    x1 = torch.randn(rows, cols).to(res_dtype) if has_x1 else None
+    w = (1 + 0.1 * torch.randn(cols)).to(w_dtype)
+    b = (0.1 * torch.randn(cols)).to(w_dtype)
+    dz = torch.randn(rows, cols).to(dtype)
+    dxr = torch.randn(rows, cols).to(res_dtype) if prenorm else None
+
+    def run(x0_, x1_, w_, b_, dz_, dxr_, fused):
+        x0_, w_, b_ = x0_.clone().requires_grad_(), w_.clone().requires_grad_(), b_.clone().requires_grad_()
+        x1_ = x1_.clone().requires_grad_() if x1_ is not None else None
+        if fused:
+            out = dropout_add_layer_norm(x0_, x1_, w_, b_, 0.0, 1e-5, prenorm=prenorm,
+                                         residual_in_fp32=(mode == 'no_residual_fp32_stream'))
+            z, xs = out if prenorm else (out, None)
+        else:
+            xs = x0_.to(x1_.dtype if x1_ is not None else x0_.dtype) + (x1_ if x1_ is not None else 0)
+            z = torch.nn.functional.layer_norm(xs.to(w_.dtype if w_.dtype == torch.float32 else xs.dtype),
+                                               (cols,), w_, b_, 1e-5).to(x0_.dtype)
+        outs, grads = [z], [dz_.to(z.dtype)]
+        if prenorm:
+            outs.append(xs)
+            grads.append(dxr_.to(xs.dtype))
+        ins = [x0_, w_, b_] + ([x1_] if x1_ is not None else [])
+        return torch.autograd.grad(outs, ins, grads)
+
+    f32 = lambda t: t.float() if t is not None else None
+    ref = run(f32(x0), f32(x1), f32(w), f32(b), f32(dz), f32(dxr), fused=False)
+    pt = run(x0, x1, w, b, dz, dxr, fused=False)
+    dev = lambda t: t.to(DEV) if t is not None else None
+    got = run(dev(x0), dev(x1), dev(w), dev(b), dev(dz), dev(dxr), fused=True)
+    names = ['dx0', 'dweight', 'dbias'] + (['dx1'] if has_x1 else [])
+    for g, r, e, n in zip(got, ref, pt, names):
+        err = (g.float().cpu() - r).abs().max().item()
+        base = (e.float() - r).abs().max().item()
+        factor, atol = (4, 1e-4) if n.startswith('dx') else (2, 2e-4 * max(1.0, r.abs().max().item()))
+        assert torch.isfinite(g.float()).all()
+        assert err <= factor * base + atol, (n, err, base)
+    assert got[0].dtype == dtype and got[1].dtype == w_dtype
+    if has_x1:
+        assert got[3].dtype == res_dtype
+
+
+def test_add_layer_norm_backward_is_deterministic():
+    from flash_attn.ops.layer_norm import dropout_add_layer_norm
+    torch.manual_seed(8)
+    x0 = torch.randn(5000, 768, device=DEV).bfloat16().requires_grad_()
+    x1 = torch.randn(5000, 768, device=DEV).requires_grad_()
+    w = torch.randn(768, device=DEV).requires_grad_()
+    b = torch.randn(768, device=DEV).requires_grad_()
+    dz = torch.randn(5000, 768, device=DEV).bfloat16()
+
+    def grads():
+        z = dropout_add_layer_norm(x0, x1, w, b, 0.0, 1e-5)
+        return torch.autograd.grad(z, [x0, x1, w, b], dz)
+    first = grads()
+    for _ in range(3):
+        for a, c in zip(first, grads()):
+            assert torch.equal(a, c)
