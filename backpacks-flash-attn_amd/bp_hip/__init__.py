@@ -31,6 +31,7 @@ SIGNATURES = {
     'bp_sense_mix': (_i32, [_ptr] * 4 + [_i32] * 6 + [_i64] * 9 + [_f32, _i32, _ptr]),
     'bp_sense_mix_weighted': (_i32, [_ptr] * 5 + [_i32] * 6 + [_i64] * 11 + [_f32, _i32, _ptr]),
     'bp_add_layer_norm': (_i32, [_ptr] * 6 + [_i64, _i32, _f32] + [_i32] * 4 + [_ptr]),
+    'bp_softmax_bwd_causal': (_i32, [_ptr, _ptr, _i64, _i32, _f32, _i32, _ptr]),
     'bp_add_layer_norm_bwd': (_i32, [_ptr] * 9 + [_i64, _i32, _f32, _i32, _i32, _i32, _ptr]),
     'bp_xentropy_fwd': (_i32, [_ptr] * 4 + [_i64, _i32, _i64, _f32, _i32, _i32, _ptr]),
     'bp_xentropy_bwd': (_i32, [_ptr] * 5 + [_i64, _i32, _i64, _i64, _f32, _i32, _i32, _ptr]),
@@ -329,6 +330,112 @@ def add_layer_norm(x0, x1, weight, bias, eps, residual_dtype=None, return_residu
             int(weight.dtype == torch.float32), _stream())
     _check(code, 'bp_add_layer_norm')
     return (z, xo) if return_residual else z
+
+
+def softmax_bwd_causal_supported(alpha):
+    return alpha.is_cuda and alpha.dtype in (torch.float16, torch.bfloat16) and alpha.shape[-1] % 8 == 0 \
+        and alpha.shape[-1] <= 4096
+
+
+def softmax_bwd_causal_(alpha, dalpha, softmax_scale):
+    """In place: dalpha (..., S, S) <- scale * alpha * (dalpha - rowsum(alpha * dalpha)) below/on the diagonal,
+    0 above it.  alpha as returned by sense_alpha.  Returns dalpha (now the gradient of the raw scores q.k)."""
+    _require_cuda(alpha, dalpha)
+    if alpha.shape != dalpha.shape or alpha.dtype != dalpha.dtype or not alpha.is_contiguous() \
+            or not dalpha.is_contiguous() or alpha.shape[-1] != alpha.shape[-2]:
+        raise RuntimeError('bp_hip.softmax_bwd_causal_: alpha and dalpha must be equal-shaped contiguous (..., S, S)')
+    s = alpha.shape[-1]
+    with torch.cuda.device(alpha.device):
+        code = lib().bp_softmax_bwd_causal(alpha.data_ptr(), dalpha.data_ptr(), alpha.numel() // (s * s), s,
+                                           float(softmax_scale), _dtype_code(alpha), _stream())
+    _check(code, 'bp_softmax_bwd_causal')
+    return dalpha
+
+
+class SenseMixFn(torch.autograd.Function):
+    """Differentiable fused sense contraction.  Forward: LSE pre-pass + bp_sense_mix_weighted (alpha never
+    stored).  Backward (second half): alpha is rebuilt once by bp_sense_alpha from the
+    saved LSE, the two vocabulary-free big products run as batched GEMMs,
+        dC_l = (alpha_l * w_l)^T dout        dA_l = dout C_l^T (* w_l)
+    bp_softmax_bwd_causal turns dA into the score gradient in place, and two thin GEMMs give dq_l, dk_l.
+    Memory: two (B,k,S,S) 16-bit buffers during backward only; the reference's autograd keeps three in fp32
+    alive from the forward on."""
+
+    @staticmethod
+    def forward(ctx, qk, content, softmax_scale, key_weight):
+        scale = softmax_scale or qk.shape[-1] ** -0.5
+        lse = sense_lse(qk, scale)
+        out = sense_mix(qk, content, scale, lse=lse, key_weight=key_weight)
+        ctx.save_for_backward(qk, content, lse, key_weight)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qk, content, lse, key_weight = ctx.saved_tensors
+        b, s, _, k, dk = qk.shape
+        dout = dout.contiguous()
+        alpha = sense_alpha(qk, ctx.scale, lse=lse)                               # (B,k,S,S)
+        weighted = alpha if key_weight is None else alpha * key_weight.unsqueeze(2).to(alpha.dtype)
+        g = dout.unsqueeze(1)                                                      # (B,1,S,d)
+        dcontent = None
+        if ctx.needs_input_grad[1]:
+            dcontent = torch.matmul(weighted.transpose(2, 3), g).transpose(1, 2)   # (B,S,k,d) view of (B,k,S,d)
+        dqk = None
+        if ctx.needs_input_grad[0]:
+            dalpha = torch.matmul(g, content.permute(0, 2, 3, 1))                  # (B,k,S_t,S_s)
+            if key_weight is not None:
+                dalpha = dalpha * key_weight.unsqueeze(2).to(dalpha.dtype)
+            dalpha = dalpha.contiguous()
+            if softmax_bwd_causal_supported(alpha):
+                ds = softmax_bwd_causal_(alpha, dalpha, ctx.scale)
+            else:
+                a32, d32 = alpha.float(), dalpha.float()
+                ds = (ctx.scale * a32 * (d32 - (a32 * d32).sum(-1, keepdim=True))).to(alpha.dtype)
+            q, kk = qk[:, :, 0].transpose(1, 2), qk[:, :, 1].transpose(1, 2)       # (B,k,S,dk)
+            dq = torch.matmul(ds, kk)
+            dkk = torch.matmul(ds.transpose(2, 3), q)
+            dqk = torch.stack([dq.transpose(1, 2), dkk.transpose(1, 2)], dim=2)   # (B,S,2,k,dk)
+        return dqk, dcontent, None, None
+
+
+def sense_mix_autograd(qk, content, softmax_scale=None, key_weight=None):
+    """sense_mix that records a backward when gradients are enabled (training), the plain kernel otherwise."""
+    if torch.is_grad_enabled() and (qk.requires_grad or content.requires_grad):
+        return SenseMixFn.apply(qk, content, softmax_scale, key_weight)
+    return sense_mix(qk, content, softmax_scale, key_weight=key_weight)
+
+
+class SenseAlphaFn(torch.autograd.Function):
+    """Differentiable bp_sense_alpha: backward = bp_softmax_bwd_causal + the two thin GEMMs."""
+
+    @staticmethod
+    def forward(ctx, qk, softmax_scale):
+        scale = softmax_scale or qk.shape[-1] ** -0.5
+        alpha = sense_alpha(qk, scale)
+        ctx.save_for_backward(qk, alpha)
+        ctx.scale = scale
+        return alpha
+
+    @staticmethod
+    def backward(ctx, dalpha):
+        qk, alpha = ctx.saved_tensors
+        dalpha = dalpha.contiguous().clone()
+        if softmax_bwd_causal_supported(alpha):
+            ds = softmax_bwd_causal_(alpha, dalpha, ctx.scale)
+        else:
+            a32, d32 = alpha.float(), dalpha.float()
+            ds = (ctx.scale * a32 * (d32 - (a32 * d32).sum(-1, keepdim=True))).to(alpha.dtype)
+        q, kk = qk[:, :, 0].transpose(1, 2), qk[:, :, 1].transpose(1, 2)
+        dq = torch.matmul(ds, kk)
+        dkk = torch.matmul(ds.transpose(2, 3), q)
+        return torch.stack([dq.transpose(1, 2), dkk.transpose(1, 2)], dim=2), None
+
+
+def sense_alpha_autograd(qk, softmax_scale=None):
+    if torch.is_grad_enabled() and qk.requires_grad:
+        return SenseAlphaFn.apply(qk, softmax_scale)
+    return sense_alpha(qk, softmax_scale)
 
 
 LN_BWD_WS_ROWS = 1024

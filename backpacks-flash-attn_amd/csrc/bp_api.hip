@@ -323,6 +323,19 @@ int bp_add_layer_norm(const void *x0, const void *x1, const void *gamma, const v
     return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
 }
 
+int bp_softmax_bwd_causal(const void *alpha, void *dalpha_inout, int64_t n_matrices, int seqlen,
+                          float softmax_scale, int dtype, bp_stream_t stream) {
+    if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
+    if (n_matrices <= 0 || seqlen <= 0 || seqlen % 8 != 0 || seqlen > 4096) return BP_ERR_SHAPE;
+    if (alpha == nullptr || dalpha_inout == nullptr || !aligned16(alpha) || !aligned16(dalpha_inout)) return BP_ERR_SHAPE;
+    if (!scale_ok(softmax_scale)) return BP_ERR_SCALE;
+    bp::SoftmaxBwdParams p{};
+    p.alpha = alpha; p.dp = dalpha_inout; p.rows = n_matrices * seqlen; p.s = seqlen; p.scale = softmax_scale;
+    hipError_t e = bp::launch_softmax_bwd_causal(p, dtype, static_cast<hipStream_t>(stream));
+    if (e == hipErrorNotSupported) return BP_ERR_SHAPE;
+    return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
+}
+
 int bp_add_layer_norm_bwd(const void *dz, const void *dx_in, const void *x, const void *gamma,
                           void *dx0, void *dx1, void *dgamma, void *dbeta, float *ws,
                           int64_t rows, int cols, float epsilon, int dtype, int res_is_f32, int w_is_f32,

@@ -70,6 +70,15 @@ struct MixParams {
     float scale_log2e;
 };
 
+struct SoftmaxBwdParams {
+    const void *alpha;   // (n, s, s) 16-bit causal softmax output (zeros above the diagonal)
+    void *dp;            // (n, s, s) 16-bit: gradient w.r.t. alpha in, gradient w.r.t. the scores out
+    int64_t rows;        // n * s
+    int s;
+    float scale;
+};
+hipError_t launch_softmax_bwd_causal(const SoftmaxBwdParams &p, int dtype, hipStream_t stream);
+
 struct XentParams {
     const void *logits;        // (rows, cols), row stride in elements, last stride 1
     const int64_t *labels;     // (rows)

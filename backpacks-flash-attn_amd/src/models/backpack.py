@@ -98,7 +98,7 @@ class ContextSelfAttn(nn.Module):
     def forward(self, encoded):
         qk = self.project(encoded)
         if self.use_hip:
-            return bp_hip.sense_alpha(qk, self.softmax_scale)
+            return bp_hip.sense_alpha_autograd(qk, self.softmax_scale)
         seqlen = qk.shape[1]
         q, k = qk.unbind(dim=2)
         scale = self.softmax_scale or 1.0 / math.sqrt(q.shape[-1])
@@ -183,8 +183,8 @@ class BackpackModel(GPTPreTrainedModel):
         if self.use_hip:
             # fused: softmax_causal(q_l k_l^T) @ C_l summed over senses, alpha never stored
             qk = self.contextualization_attn.project(contextl_hidden_states)
-            return bp_hip.sense_mix(qk, content.transpose(1, 2),
-                                    self.contextualization_attn.softmax_scale)
+            return bp_hip.sense_mix_autograd(qk, content.transpose(1, 2),
+                                             self.contextualization_attn.softmax_scale)
         contextualization = self.contextualization_attn(contextl_hidden_states)   # (B,k,S,S)
         return torch.sum(contextualization @ content, dim=1)                       # (B,S,d)
 

@@ -205,6 +205,17 @@ int bp_add_layer_norm(const void *x0, const void *x1, const void *gamma, const v
                       int xout_is_f32, int w_is_f32, bp_stream_t stream);
 
 /*
+ * bp_softmax_bwd_causal -- backward of the causal softmax behind the sense weights (training path of
+ * ContextSelfAttn.forward, training/src/models/backpack.py:112-122, which the reference leaves to autograd):
+ *   dscores[n,t,s] = scale * alpha[n,t,s] * (dalpha[n,t,s] - sum_{s'<=t} alpha[n,t,s'] dalpha[n,t,s'])  for s <= t,
+ *   0 above the diagonal.  In place: `dalpha_inout` holds dalpha on entry and dscores on return.
+ *   alpha, dalpha_inout  (n_matrices, seqlen, seqlen) 16-bit contiguous, 16-byte aligned;
+ *   seqlen % 8 == 0 and <= 4096 (BP_ERR_SHAPE otherwise)
+ */
+int bp_softmax_bwd_causal(const void *alpha, void *dalpha_inout, int64_t n_matrices, int seqlen,
+                          float softmax_scale, int dtype, bp_stream_t stream);
+
+/*
  * bp_add_layer_norm_bwd -- backward of bp_add_layer_norm (eval-path subset of the reference's
  * dropout_add_ln_bwd, csrc/layer_norm/ln_api.cpp:256-408; Python side flash_attn/ops/layer_norm.py:131-152):
  *   dx = rs (dz*gamma - mean(dz*gamma) - xhat mean(dz*gamma*xhat)) + dx_in ;  dgamma = sum dz*xhat ; dbeta = sum dz

@@ -210,3 +210,112 @@ def test_autograd_functions_use_backward(packing, d):
         got = [q.grad, k.grad, v.grad]
     got = [g.reshape(b, s, h, d) for g in got]
     _check(got, ref, eager, f'autograd {packing} d={d}')
+
+
+# ---------------------------------------------------------------------------------------------
+# Sense contraction backward (row 1, second half): bp_softmax_bwd_causal + the autograd Functions
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('s', [8, 64, 200, 1024, 2048])
+def test_softmax_bwd_causal_kernel(s, dtype):
+    bp = _bp()
+    torch.manual_seed(11)
+    n = 6
+    scores = torch.randn(n, s, s) * 2
+    mask = torch.ones(s, s, dtype=torch.bool).triu(1)
+    alpha32 = torch.softmax(scores.masked_fill(mask, float('-inf')), -1)
+    alpha = alpha32.to(dtype)
+    dalpha = torch.randn(n, s, s).to(dtype)
+    dalpha_garbage = dalpha.clone()
+    dalpha_garbage[:, mask] = 777.0                     # what a GEMM leaves above the diagonal
+    a32, d32 = alpha.float(), dalpha.float()
+    want = 0.37 * a32 * (d32 - (a32 * d32.masked_fill(mask, 0)).sum(-1, keepdim=True))
+    got = bp.softmax_bwd_causal_(alpha.to(DEV), dalpha_garbage.to(DEV), 0.37)
+    assert torch.equal(got.cpu()[:, mask], torch.zeros_like(got.cpu()[:, mask]))
+    tol = 2e-2 if dtype == torch.bfloat16 else 3e-3
+    assert (got.float().cpu() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
+
+
+def _mix_grads(qk, c_st, dout, w, fused):
+    """Gradients of sum_l (alpha_l * w_l) @ C_l w.r.t. qk (B,S,2,k,dk) and content storage (B,S,k,d)."""
+    qk = qk.clone().requires_grad_()
+    c_st = c_st.clone().requires_grad_()
+    if fused:
+        out = _bp().sense_mix_autograd(qk, c_st, None, key_weight=w)
+    else:
+        alpha = R.sense_alpha_from_qk(qk)
+        c = c_st.transpose(1, 2)
+        if w is not None:
+            c = c * w.unsqueeze(3).to(c.dtype)
+        out = R.sense_mix(alpha, c)
+    return torch.autograd.grad(out, (qk, c_st), dout.to(out.dtype))
+
+
+@pytest.mark.parametrize('weighted', [False, True])
+@pytest.mark.parametrize('shape', [(2, 200, 16, 48, 768), (1, 96, 4, 24, 104), (2, 130, 64, 10, 640)])
+def test_sense_mix_backward(shape, weighted):
+    """loss.backward() through the fused contraction: dqk and dcontent against fp32 autograd of the oracle,
+    eager bf16 autograd as yardstick (factor 2 + small floor, tests/test_flash_attn.py:391-397 style)."""
+    b, s, k, dk, d = shape
+    torch.manual_seed(12)
+    qk = (torch.randn(b, s, 2, k, dk) * 1.2).bfloat16()
+    c = torch.randn(b, s, k, d).bfloat16()
+    dout = torch.randn(b, s, d).bfloat16()
+    w = (torch.rand(b, k, s) * 2.0) if weighted else None
+    ref = _mix_grads(qk.float(), c.float(), dout.float(), w, fused=False)
+    eager = _mix_grads(qk, c, dout, w, fused=False)
+    got = _mix_grads(qk.to(DEV), c.to(DEV), dout.to(DEV), w.to(DEV) if weighted else None, fused=True)
+    for g, r, e, name in zip(got, ref, eager, ('dqk', 'dcontent')):
+        err = (g.float().cpu() - r).abs().max().item()
+        base = (e.float() - r).abs().max().item()
+        print(f'mix bwd {shape} weighted={weighted} {name}: hip {err:.3e} eager {base:.3e}')
+        assert g.shape == r.shape and torch.isfinite(g.float()).all()
+        assert err <= 2 * base + 1e-3 * max(1.0, r.abs().max().item()), (name, err, base)
+
+
+def test_backpack_training_step_on_the_hip_path():
+    """Whole model, use_flash_attn + fused flags: loss.backward() reaches every parameter through the HIP
+    kernels (flash bwd, sense-mix bwd, LayerNorm bwd, fused CE) and matches the fp32 CPU model."""
+    from flash_attn.losses.cross_entropy import CrossEntropyLoss
+    from src.models.backpack import BackpackConfig, BackpackLMHeadModel
+    kw = dict(n_embd=128, n_head=2, n_layer=2, num_content_vectors=4, vocab_size=512, n_positions=64,
+              scale_attn_by_inverse_layer_idx=True, resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0,
+              pad_vocab_size_multiple=8)
+    torch.manual_seed(13)
+    ref = BackpackLMHeadModel(BackpackConfig(use_flash_attn=False, **kw)).train()
+    with torch.no_grad():
+        ref.transformer.contextualization_attn.Wqkv.weight.mul_(6.0)
+    hip = BackpackLMHeadModel(BackpackConfig(use_flash_attn=True, fused_dropout_add_ln=True, fused_bias_fc=True,
+                                             fused_dense_gelu_dense=True, **kw)).train()
+    hip.load_state_dict(ref.state_dict())
+    hip = hip.to(DEV, torch.bfloat16)
+    low = BackpackLMHeadModel(BackpackConfig(use_flash_attn=False, **kw)).train()
+    low.load_state_dict(ref.state_dict())
+    low = low.to(torch.bfloat16)
+    ids = torch.randint(0, 512, (3, 64))
+    labels = torch.roll(ids, -1, 1)
+
+    def step(model, x, y, fused_loss):
+        logits = model(x).logits
+        flat = logits.reshape(-1, logits.shape[-1])
+        if fused_loss:
+            loss = CrossEntropyLoss()(flat, y.reshape(-1))
+        else:
+            loss = torch.nn.functional.cross_entropy(flat.float(), y.reshape(-1))
+        loss.backward()
+        return loss.item()
+
+    l_ref = step(ref, ids, labels, False)
+    l_low = step(low, ids, labels, False)
+    l_hip = step(hip, ids.to(DEV), labels.to(DEV), True)
+    assert abs(l_hip - l_ref) <= 3 * abs(l_low - l_ref) + 2e-2
+    worst = 0.0
+    for (name, p_ref), p_low, p_hip in zip(ref.named_parameters(), low.parameters(), hip.parameters()):
+        assert p_hip.grad is not None, name
+        r = p_ref.grad
+        err = (p_hip.grad.float().cpu() - r).abs().max().item()
+        base = (p_low.grad.float() - r).abs().max().item()
+        scale = max(r.abs().max().item(), 1e-6)
+        worst = max(worst, err / scale)
+        assert err <= 4 * base + 2e-2 * scale, (name, err, base, scale)
+    print('training step: loss', l_ref, l_hip, 'worst relative grad error', worst)
