@@ -1,0 +1,83 @@
+"""BASELINE config 3 (Backpack-Small, seq 1024, bf16, DDP): one training step = forward + fused cross-entropy +
+backward (+ gradient all-reduce under DDP) + AdamW step, timed.  NOT the headline bench (that is bench.py, the
+forward metric); this script records what the training path costs on the HIP kernels.
+
+    python scripts/bench_train_step.py [--batch 16] [--steps 5] [--model small]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 scripts/bench_train_step.py
+Weights fp32 master copies are not kept (the reference trains with bf16 autocast over fp32 weights; here the
+model is bf16 and AdamW runs on bf16 parameters -- a throughput probe, not a recipe)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'backpacks-flash-attn_amd')):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--seq', type=int, default=1024)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--model', default='small')
+    a = ap.parse_args()
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+    from bench import MODELS
+    from flash_attn.losses.cross_entropy import CrossEntropyLoss
+    from src.models.backpack import BackpackConfig, BackpackLMHeadModel
+    cfg = BackpackConfig(vocab_size=50257, n_positions=a.seq, scale_attn_by_inverse_layer_idx=True,
+                         use_flash_attn=True, fused_bias_fc=True, fused_dense_gelu_dense=True,
+                         fused_dropout_add_ln=True, pad_vocab_size_multiple=8, resid_pdrop=0.0, embd_pdrop=0.0,
+                         attn_pdrop=0.0, **MODELS[a.model])
+    torch.manual_seed(0)
+    model = BackpackLMHeadModel(cfg, device=dev, dtype=torch.bfloat16).train()
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True,
+                                                        find_unused_parameters=False)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True)
+    loss_fn = CrossEntropyLoss(inplace_backward=True)
+    ids = torch.randint(0, 50257, (a.batch, a.seq), device=dev, generator=torch.Generator(device=dev).manual_seed(rank))
+    labels = torch.roll(ids, -1, 1)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        logits = net(ids).logits
+        loss = loss_fn(logits.view(-1, logits.shape[-1]), labels.view(-1))
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({'metric': f'tokens/sec train step (fwd+loss+bwd+AdamW), Backpack-{a.model} seq={a.seq}',
+                          'value': round(world * a.batch * a.seq * a.steps / dt, 1), 'unit': 'tokens/s',
+                          'n_gpus': world, 'ms_per_step': round(dt / a.steps * 1e3, 2), 'batch_per_gpu': a.batch,
+                          'dtype': 'bf16', 'loss': round(float(loss.detach()), 4),
+                          'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}))
+
+
+if __name__ == '__main__':
+    main()
