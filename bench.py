@@ -85,10 +85,10 @@ def instrument(clock):
     t_lse = clock.wrap('flash_fwd_kernel[lse-only,senses]', raw_lse)
     t_mix = clock.wrap('sense_mix_kernel', raw_mix)
 
-    def mix_two_launches(qk, content, softmax_scale=None, out=None, lse=None):
+    def mix_two_launches(qk, content, softmax_scale=None, out=None, lse=None, key_weight=None):
         if lse is None:
             lse = t_lse(qk, softmax_scale)
-        return t_mix(qk, content, softmax_scale, out=out, lse=lse)
+        return t_mix(qk, content, softmax_scale, out=out, lse=lse, key_weight=key_weight)
 
     bp_hip.flash_fwd = t_flash
     bp_hip.sense_mix = mix_two_launches

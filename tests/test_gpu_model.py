@@ -244,3 +244,25 @@ def test_intervened_models_hip_vs_oracle():
         err, ref = (got.float().cpu() - want).abs().max().item(), (base.float() - want).abs().max().item()
         print(f'replaced: hip {err:.3e} eager-bf16 {ref:.3e}')
         assert err <= 3 * ref + 2e-3
+
+
+def test_bench_script_contract():
+    """bench.py runs end to end (small workload) and prints ONE JSON line carrying the driver's contract keys,
+    the roofline object of the dominant attention-path kernel and per-kernel HIP-event timings."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', 'micro-128', '--steps', '3',
+                          '--warmup', '1', '--no-cpu-baseline'], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'kernels'):
+        assert key in d, key
+    assert d['n_gpus'] == 1 and d['steps'] == 3 and d['value'] > 0 and d['vs_baseline'] is None
+    assert set(d['roofline']) >= {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'}
+    assert {k['kernel'] for k in d['kernels']} >= {'flash_fwd_kernel', 'sense_mix_kernel', 'add_layer_norm_kernel'}
