@@ -89,6 +89,7 @@ int bp_flash_fwd(const void *q, const void *k, const void *v, void *out, float *
     p.max_sq = max_seqlen_q; p.max_sk = max_seqlen_k;
     p.n_qtiles = (max_seqlen_q + 127) / 128;
     p.causal = is_causal ? 1 : 0;
+    p.pair = (p.causal && p.n_qtiles > 1 && !env_is("BP_FLASH_PAIR", "0")) ? 1 : 0;
     p.scale_log2e = softmax_scale * bp::kLog2e;
 
     bool vec = (head_dim % 8 == 0) && aligned16(q) && aligned16(k) && mult8(q_row_stride) &&
@@ -149,6 +150,7 @@ static int sense_lse(const void *qk, float *lse_ws, int batch, int seqlen, int n
     p.max_sq = seqlen; p.max_sk = seqlen;
     p.n_qtiles = (seqlen + 127) / 128;
     p.causal = 1;
+    p.pair = (p.n_qtiles > 1 && !env_is("BP_FLASH_PAIR", "0")) ? 1 : 0;
     p.scale_log2e = softmax_scale * bp::kLog2e;
     const bool vec = (d_k % 8 == 0) && aligned16(qp) && aligned16(kp) && mult8(qk_bs) && mult8(qk_rs) &&
                      mult8(qk_ss);

@@ -19,6 +19,7 @@ struct FlashParams {
     int max_sq, max_sk;
     int n_qtiles;             // ceil(max_sq / 128)
     int causal;
+    int pair;                 // flash_fwd_dma: one workgroup takes query tiles t and n-1-t (causal load balance)
     float scale_log2e;        // softmax_scale * log2(e)
     unsigned long long *prof; // BP_PROFILE_PHASES debug builds only (8 u64 per wave), else NULL
 };

@@ -40,11 +40,11 @@ struct FlashDmaCfg {
     static constexpr int K_ROWS_PER_DMA = 1024 / KROW;
 };
 
+// One 128-query tile `qt` of (sample, head) `bh`: the whole online-softmax sweep over its key tiles.
 template <class ET, int KD, int NV, bool HAS_V>
-__global__ __launch_bounds__(256, BP_FLASH_MINWAVES) void flash_fwd_dma_kernel(const FlashParams p) {
+BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0, const int bh, const int qt) {
     using C = FlashDmaCfg<KD, NV, HAS_V>;
     using E = Elem<ET>;
-    __shared__ __attribute__((aligned(16))) char smem[C::NSTAGE * C::STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -52,9 +52,6 @@ __global__ __launch_bounds__(256, BP_FLASH_MINWAVES) void flash_fwd_dma_kernel(c
     const int l31 = lane & 31;
     const int hh = lane >> 5;
 
-    int bh, slot;
-    if (!xcd_map(blockIdx.x, p.b * p.h, p.n_qtiles, bh, slot)) return;
-    const int qt = p.n_qtiles - 1 - slot;
     const int batch = bh / p.h;
     const int head = bh - batch * p.h;
 
@@ -132,7 +129,6 @@ __global__ __launch_bounds__(256, BP_FLASH_MINWAVES) void flash_fwd_dma_kernel(c
             v_voff[j] = (uint32_t)(row * p.v_rs + v_col[j]) * 2u;
         }
     }
-    const uint32_t lds0 = lds_base_addr(smem);
     // Full tiles: scalar base (+= 64 rows per tile) + constant per-lane byte offset -> no VALU at all.
     // The last, partial tile clamps its rows to the final valid one (those keys are masked later).
     auto issue = [&](int kb) {
@@ -380,9 +376,32 @@ __global__ __launch_bounds__(256, BP_FLASH_MINWAVES) void flash_fwd_dma_kernel(c
     }
 }
 
+// Work order.  The dispatcher hands workgroups to the CUs of an XCD strictly round-robin and IN ORDER: block
+// i+1 is not placed before block i, and block i waits for a free slot on ITS CU even when other CUs idle
+// (scripts/probes/dispatch_order.hip).  With causal tiles of 1..n key blocks in block order, a CU keeps getting
+// the same tile length and the short ones wait for the long ones: 64 time units instead of 36 for S = 1024 in a
+// model of that dispatcher, and 8.3 vs 5.9 ms in the probe.  So a causal workgroup takes TWO query tiles of its
+// (sample, head), the heaviest remaining and the lightest (t and n-1-t): every workgroup then carries the same
+// n+1 key blocks, nothing waits, and both tiles still belong to one group, i.e. one XCD's L2 holds their K/V.
+template <class ET, int KD, int NV, bool HAS_V>
+__global__ __launch_bounds__(256, BP_FLASH_MINWAVES) void flash_fwd_dma_kernel(const FlashParams p) {
+    using C = FlashDmaCfg<KD, NV, HAS_V>;
+    __shared__ __attribute__((aligned(16))) char smem[C::NSTAGE * C::STAGE];
+    const uint32_t lds0 = lds_base_addr(smem);
+    const int per_group = p.pair ? (p.n_qtiles + 1) / 2 : p.n_qtiles;
+    int bh, slot;
+    if (!xcd_map(blockIdx.x, p.b * p.h, per_group, bh, slot)) return;
+    const int heavy = p.n_qtiles - 1 - slot;
+    const int npass = (p.pair && slot != heavy) ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+        if (pass) __syncthreads();   // every wave is done with the ring before the next tile's DMA refills it
+        flash_fwd_tile<ET, KD, NV, HAS_V>(p, smem, lds0, bh, pass ? slot : heavy);
+    }
+}
+
 template <class ET, int KD, int NV, bool HAS_V>
 static hipError_t launch_one(const FlashParams &p, hipStream_t stream) {
-    const int grid = xcd_grid(p.b * p.h, p.n_qtiles);
+    const int grid = xcd_grid(p.b * p.h, p.pair ? (p.n_qtiles + 1) / 2 : p.n_qtiles);
     hipLaunchKernelGGL((flash_fwd_dma_kernel<ET, KD, NV, HAS_V>), dim3(grid), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
