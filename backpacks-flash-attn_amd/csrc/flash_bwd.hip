@@ -66,15 +66,23 @@ BP_DEV void t_piece(int wave, int lane, int j, int &row, int &col) {
 // =====================================================================================================
 // dK, dV
 // =====================================================================================================
+template <int KD, int NV>
+struct DkdvCfg {
+    using C = BwdCfg<KD, NV>;
+    // stage = Q row image | Q transposed-read image | dO row image | dO transposed-read image | stats
+    static constexpr int STATS = 4 * 512;   // per wave: 64 x lse2, 64 x D (fp32)
+    static constexpr int STAGE = 2 * C::RTILE + 2 * C::TTILE + STATS;
+    static constexpr int SMEM = C::NSTAGE * STAGE;
+};
+
+// one 128-key tile `kt` of (sample, head) `bh`
 template <class ET, int KD, int NV>
-__global__ __launch_bounds__(256) void flash_bwd_dkdv_kernel(const FlashBwdParams p) {
+BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32_t lds0, const int bh, const int kt) {
     using C = BwdCfg<KD, NV>;
     using E = Elem<ET>;
-    // stage = Q row image | Q transposed-read image | dO row image | dO transposed-read image | stats
-    constexpr int STATS = 4 * 512;   // per wave: 64 x lse2, 64 x D (fp32)
-    constexpr int STAGE = 2 * C::RTILE + 2 * C::TTILE + STATS;
+    constexpr int STATS = DkdvCfg<KD, NV>::STATS;
+    constexpr int STAGE = DkdvCfg<KD, NV>::STAGE;
     constexpr int DMA_PER_STAGE = 2 * C::R_DMA + 2 * C::T_DMA + 1;
-    __shared__ __attribute__((aligned(16))) char smem[C::NSTAGE * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -82,9 +90,6 @@ __global__ __launch_bounds__(256) void flash_bwd_dkdv_kernel(const FlashBwdParam
     const int l31 = lane & 31;
     const int hh = lane >> 5;
 
-    const int n_ktiles = (p.max_sk + 127) / 128;
-    int bh, kt;
-    if (!xcd_map(blockIdx.x, p.b * p.h, n_ktiles, bh, kt)) return;   // first key tile = most work first
     const int batch = bh / p.h;
     const int head = bh - batch * p.h;
 
@@ -147,7 +152,6 @@ __global__ __launch_bounds__(256) void flash_bwd_dkdv_kernel(const FlashBwdParam
     for (int j = 0; j < C::R_DMA; ++j) r_piece<C>(wave, lane, j, rr[j], rc[j]);
 #pragma unroll
     for (int j = 0; j < C::T_DMA; ++j) t_piece<C, NV>(wave, lane, j, tr[j], tc[j]);
-    const uint32_t lds0 = lds_base_addr(smem);
     auto issue = [&](int qt) {
         const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + ((qt - qt_begin) % C::NSTAGE) * STAGE);
         const int row_base = qt * C::BT;
@@ -279,13 +283,13 @@ __global__ __launch_bounds__(256) void flash_bwd_dkdv_kernel(const FlashBwdParam
 // =====================================================================================================
 // dQ
 // =====================================================================================================
+// one 128-query tile `qt` of (sample, head) `bh`
 template <class ET, int KD, int NV>
-__global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashBwdParams p) {
+BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t lds0, const int bh, const int qt) {
     using C = BwdCfg<KD, NV>;
     using E = Elem<ET>;
     // stage = K row image | K transposed-read image | V row image
     constexpr int STAGE = 2 * C::RTILE + C::TTILE;
-    __shared__ __attribute__((aligned(16))) char smem[C::NSTAGE * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -293,10 +297,6 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashBwdParams 
     const int l31 = lane & 31;
     const int hh = lane >> 5;
 
-    const int n_qtiles = (p.max_sq + 127) / 128;
-    int bh, slot;
-    if (!xcd_map(blockIdx.x, p.b * p.h, n_qtiles, bh, slot)) return;
-    const int qt = n_qtiles - 1 - slot;
     const int batch = bh / p.h;
     const int head = bh - batch * p.h;
 
@@ -370,7 +370,6 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashBwdParams 
     for (int j = 0; j < C::R_DMA; ++j) r_piece<C>(wave, lane, j, rr[j], rc[j]);
 #pragma unroll
     for (int j = 0; j < C::T_DMA; ++j) t_piece<C, NV>(wave, lane, j, tr[j], tc[j]);
-    const uint32_t lds0 = lds_base_addr(smem);
     auto issue = [&](int kb) {
         const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + (kb % C::NSTAGE) * STAGE);
 #pragma unroll
@@ -474,14 +473,50 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashBwdParams 
         }
 }
 
+// Kernels: a causal workgroup takes the heaviest remaining tile and the lightest of its (sample, head) -- tiles t
+// and n-1-t -- so that every workgroup carries the same work (in-order round-robin dispatch, see flash_fwd_dma.hip).
+template <class ET, int KD, int NV>
+__global__ __launch_bounds__(256) void flash_bwd_dkdv_kernel(const FlashBwdParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[DkdvCfg<KD, NV>::SMEM];
+    const uint32_t lds0 = lds_base_addr(smem);
+    const int n = (p.max_sk + 127) / 128;
+    const bool pair = p.causal && n > 1;
+    int bh, slot;
+    if (!xcd_map(blockIdx.x, p.b * p.h, pair ? (n + 1) / 2 : n, bh, slot)) return;   // key tile 0 = most work
+    const int other = n - 1 - slot;
+    const int npass = (pair && other != slot) ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+        if (pass) __syncthreads();
+        flash_bwd_dkdv_tile<ET, KD, NV>(p, smem, lds0, bh, pass ? other : slot);
+    }
+}
+
+template <class ET, int KD, int NV>
+__global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashBwdParams p) {
+    using C = BwdCfg<KD, NV>;
+    __shared__ __attribute__((aligned(16))) char smem[C::NSTAGE * (2 * C::RTILE + C::TTILE)];
+    const uint32_t lds0 = lds_base_addr(smem);
+    const int n = (p.max_sq + 127) / 128;
+    const bool pair = p.causal && n > 1;
+    int bh, slot;
+    if (!xcd_map(blockIdx.x, p.b * p.h, pair ? (n + 1) / 2 : n, bh, slot)) return;
+    const int heavy = n - 1 - slot;
+    const int npass = (pair && heavy != slot) ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+        if (pass) __syncthreads();
+        flash_bwd_dq_tile<ET, KD, NV>(p, smem, lds0, bh, pass ? slot : heavy);
+    }
+}
+
 template <class ET, int KD, int NV>
 static hipError_t launch_one(const FlashBwdParams &p, hipStream_t stream) {
     // dq first: it also produces the D vector the dkdv kernel consumes
-    const int gq = xcd_grid(p.b * p.h, (p.max_sq + 127) / 128);
+    const int nq = (p.max_sq + 127) / 128, nk = (p.max_sk + 127) / 128;
+    const int gq = xcd_grid(p.b * p.h, (p.causal && nq > 1) ? (nq + 1) / 2 : nq);
     hipLaunchKernelGGL((flash_bwd_dq_kernel<ET, KD, NV>), dim3(gq), dim3(256), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const int gk = xcd_grid(p.b * p.h, (p.max_sk + 127) / 128);
+    const int gk = xcd_grid(p.b * p.h, (p.causal && nk > 1) ? (nk + 1) / 2 : nk);
     hipLaunchKernelGGL((flash_bwd_dkdv_kernel<ET, KD, NV>), dim3(gk), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
