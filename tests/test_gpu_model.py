@@ -266,3 +266,27 @@ def test_bench_script_contract():
     assert d['n_gpus'] == 1 and d['steps'] == 3 and d['value'] > 0 and d['vs_baseline'] is None
     assert set(d['roofline']) >= {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'}
     assert {k['kernel'] for k in d['kernels']} >= {'flash_fwd_kernel', 'sense_mix_kernel', 'add_layer_norm_kernel'}
+
+
+def test_greedy_generation_on_the_hip_path():
+    """model.generate on the HIP path (the sequence grows by one token per step, so every call meets a new,
+    unaligned sequence length): scores of every step against the fp32 CPU model fed the same prefix."""
+    from src.models.backpack import BackpackConfig, BackpackLMHeadModel
+    kw = dict(n_embd=128, n_head=2, n_layer=2, num_content_vectors=4, vocab_size=512, n_positions=48,
+              scale_attn_by_inverse_layer_idx=True, resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0,
+              pad_vocab_size_multiple=8)
+    torch.manual_seed(21)
+    ref = BackpackLMHeadModel(BackpackConfig(use_flash_attn=False, **kw)).eval()
+    hip = BackpackLMHeadModel(BackpackConfig(use_flash_attn=True, fused_dropout_add_ln=True, **kw)).eval()
+    hip.load_state_dict(ref.state_dict())
+    hip = hip.to(DEV, torch.bfloat16)
+    ids = torch.randint(0, 512, (2, 5))
+    out = hip.generate(ids.to(DEV), max_length=20, return_dict_in_generate=True, output_scores=True)
+    seq = out.sequences.cpu()
+    assert seq.shape == (2, 20) and torch.equal(seq[:, :5], ids)
+    with torch.no_grad():
+        want = ref(seq).logits                                   # teacher-forced on the generated sequence
+    for step, scores in enumerate(out.scores):                   # scores[i] predicts token 5 + i
+        got = scores.float().cpu()
+        assert (got - want[:, 4 + step, :got.shape[-1]]).abs().max().item() < 0.15
+        assert torch.equal(got.argmax(-1), seq[:, 5 + step])
