@@ -18,6 +18,9 @@
 #ifndef BP_FLASH_DEFER
 #define BP_FLASH_DEFER 8.f   // deferred-rescale threshold in exp2 units; negative = always rescale
 #endif
+#ifndef BP_FLASH_UNROLL
+#define BP_FLASH_UNROLL 1   // unroll the key loop by the ring depth: static LDS slot addresses
+#endif
 #ifndef BP_FLASH_MINWAVES
 #define BP_FLASH_MINWAVES 1
 #endif
@@ -314,7 +317,10 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
 #pragma unroll
     for (int t = 0; t < C::NSTAGE - 1; ++t)
         if (t < nkb) issue(t);
-    for (int kb = 0; kb < nkb; ++kb) {
+    // One ring step; SLOT is the ring slot as a compile-time constant when the loop is unrolled by the ring depth
+    // (BP_FLASH_UNROLL), so the LDS addresses of all operand reads fold into instruction offsets, or -1.
+    auto ring_step = [&](int kb, auto SLOT) {
+        constexpr int kSlot = decltype(SLOT)::value;
         // tiles kb+1 .. kb+NSTAGE-2 may still be in flight; tile kb must have landed
         const int later = min(nkb - 1 - kb, C::NSTAGE - 2);
 #ifndef BP_ABL_NOVMWAIT
@@ -331,14 +337,23 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
         BP_STAMP(0)
         const bool active = wave_has_rows && !(p.causal && kb * C::BN > q0 + 31);
         if (active) {
-            const char *kbuf = smem + (kb % C::NSTAGE) * C::STAGE;
+            const char *kbuf = smem + (kSlot >= 0 ? kSlot : kb % C::NSTAGE) * C::STAGE;
             const char *vbuf = kbuf + C::KTILE;
             const bool need_mask = (kb * C::BN + C::BN > seq_k) || (p.causal && kb * C::BN + C::BN - 1 > q0);
             if (need_mask) block(kb, kbuf, vbuf, std::true_type{});
             else block(kb, kbuf, vbuf, std::false_type{});
         }
         BP_STAMP(4)
+    };
+#if BP_FLASH_UNROLL
+    static_assert(C::NSTAGE == 2, "the unrolled loop assumes a 2-slot ring");
+    for (int kb = 0; kb < nkb; kb += 2) {
+        ring_step(kb, std::integral_constant<int, 0>{});
+        if (kb + 1 < nkb) ring_step(kb + 1, std::integral_constant<int, 1>{});
     }
+#else
+    for (int kb = 0; kb < nkb; ++kb) ring_step(kb, std::integral_constant<int, -1>{});
+#endif
 #ifdef BP_PROFILE_PHASES
     if (lane == 0 && p.o_bs == -12345) {   // never true: keeps the stamps alive without touching outputs
         p.lse[0] = (float)(ph[0] + ph[1] + ph[2] + ph[3] + ph[4]);
