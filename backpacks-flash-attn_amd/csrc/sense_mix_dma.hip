@@ -283,7 +283,10 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
     if (nsteps > 1) issue(1, cur1);
     advance(cur2);
 
-    for (int step = 0; step < nsteps; ++step) {
+    // One pipeline step.  SLOT: the ring slot as a compile-time constant (the loop below is unrolled by the ring
+    // depth so that the LDS addresses of the operand reads fold into instruction offsets).
+    auto ring_step = [&](int step, auto SLOT) {
+        constexpr int kSlot = decltype(SLOT)::value;
         const int l = cur.l;
         const int kb = cur.st * sup + cur.kk;
         // my share of tile `step` (and my mailbox, which is older than tile step+1 in the queue) has
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
 #endif
 
         {
-            const int stage_off = (step % C::NSTAGE) * C::STAGE;
+            const int stage_off = kSlot * C::STAGE;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int sub = kb * 2 + kk;
@@ -400,6 +403,12 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
             }
         }
         advance(cur); advance(cur1); advance(cur2);
+    };
+    static_assert(C::NSTAGE == 3, "the unrolled loop assumes a 3-slot ring");
+    for (int step = 0; step < nsteps; step += 3) {
+        ring_step(step, std::integral_constant<int, 0>{});
+        if (step + 1 < nsteps) ring_step(step + 1, std::integral_constant<int, 1>{});
+        if (step + 2 < nsteps) ring_step(step + 2, std::integral_constant<int, 2>{});
     }
 
     if (!wave_has_rows || my_q >= S) return;
