@@ -197,12 +197,14 @@ BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32
     }
 
     if (qt_begin < nqt) issue(qt_begin);
-    for (int qt = qt_begin; qt < nqt; ++qt) {
+    // one ring step; SLOT = ring slot as a compile-time constant (loop unrolled by the ring depth: static LDS offsets)
+    auto ring_step = [&](int qt, auto SLOT) {
+        constexpr int kSlot = decltype(SLOT)::value;
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (qt + 1 < nqt) issue(qt + 1);
-        if (!wave_has_keys) continue;
-        const char *st = smem + ((qt - qt_begin) % C::NSTAGE) * STAGE;
+        if (!wave_has_keys) return;
+        const char *st = smem + kSlot * STAGE;
         const char *q_r = st, *q_t = st + C::RTILE;
         const char *do_r = st + C::RTILE + C::TTILE, *do_t = st + 2 * C::RTILE + C::TTILE;
         const char *stats = st + 2 * C::RTILE + 2 * C::TTILE + wave * 512;
@@ -260,6 +262,11 @@ BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32
                 }
             }
         }
+    };
+    static_assert(C::NSTAGE == 2, "unrolled by the 2-slot ring");
+    for (int qt = qt_begin; qt < nqt; qt += 2) {
+        ring_step(qt, std::integral_constant<int, 0>{});
+        if (qt + 1 < nqt) ring_step(qt + 1, std::integral_constant<int, 1>{});
     }
 
     if (!wave_has_keys || my_key >= seq_k) return;
@@ -405,13 +412,14 @@ BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t
     }
 
     if (nkb > 0) issue(0);
-    for (int kb = 0; kb < nkb; ++kb) {
+    auto ring_step = [&](int kb, auto SLOT) {
+        constexpr int kSlot = decltype(SLOT)::value;
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (kb + 1 < nkb) issue(kb + 1);
-        if (!wave_has_rows) continue;
-        if (p.causal && kb * C::BT > q0 + 31) continue;
-        const char *st = smem + (kb % C::NSTAGE) * STAGE;
+        if (!wave_has_rows) return;
+        if (p.causal && kb * C::BT > q0 + 31) return;
+        const char *st = smem + kSlot * STAGE;
         const char *k_r = st, *k_t = st + C::RTILE, *v_r = st + C::RTILE + C::TTILE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -456,6 +464,11 @@ BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t
                 }
             }
         }
+    };
+    static_assert(C::NSTAGE == 2, "unrolled by the 2-slot ring");
+    for (int kb = 0; kb < nkb; kb += 2) {
+        ring_step(kb, std::integral_constant<int, 0>{});
+        if (kb + 1 < nkb) ring_step(kb + 1, std::integral_constant<int, 1>{});
     }
 
     if (!wave_has_rows || my_q >= seq_q) return;
