@@ -319,3 +319,22 @@ def test_backpack_training_step_on_the_hip_path():
         worst = max(worst, err / scale)
         assert err <= 4 * base + 2e-2 * scale, (name, err, base, scale)
     print('training step: loss', l_ref, l_hip, 'worst relative grad error', worst)
+
+
+def test_fixed_length_entry_without_cu_seqlens():
+    """cu_seqlens = NULL at the C ABI (fixed-length batches, `bp_flash_fwd` / `bp_flash_bwd` header contract):
+    same bits as the varlen entry fed arange cu_seqlens."""
+    bp = _bp()
+    torch.manual_seed(31)
+    b, s, h, d = 3, 200, 2, 64
+    q, k, v, dout = (torch.randn(b * s, h, d, device=DEV).bfloat16() for _ in range(4))
+    cu = torch.arange(0, (b + 1) * s, s, dtype=torch.int32, device=DEV)
+    outs = []
+    for cu_arg in (cu, None):
+        out = torch.empty_like(q)
+        lse = bp.flash_fwd(q, k, v, out, cu_arg, cu_arg, s, s, 0.125, True)
+        dq, dk, dv = (torch.empty_like(q) for _ in range(3))
+        bp.flash_bwd(dout, q, k, v, out, lse, dq, dk, dv, cu_arg, cu_arg, s, s, 0.125, True)
+        outs.append((out, lse[..., :s], dq, dk, dv))      # LSE entries past the sequence are left untouched
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)
