@@ -1,6 +1,6 @@
 """Attention modules -- API mirror of the reference's flash_attn/modules/mha.py for the serial
 (non tensor-parallel) path: FlashSelfAttention / FlashCrossAttention (HIP kernel), their eager
-twins SelfAttention / CrossAttention (the CPU oracle path), and MHA.
+twins SelfAttention / CrossAttention (the reference's own non-fused path, any device), and MHA.
 ParallelMHA, rotary embeddings, dwconv and the Triton variants are out of scope."""
 import math
 

@@ -216,3 +216,20 @@ def test_intervened_models_match_reference_golden_on_cpu():
     assert list(inspect.signature(im.WeightedBackpackLMHeadModel.__init__).parameters)[1:] == [
         'backpack_network', 'content_weights', 'target_weight', 'annealing_scale', 'anneal', 'upweight_nearby']
     assert list(inspect.signature(im.create_content_soft_mask).parameters) == ['content_weights', 'input_ids', 'scores']
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under the package, bench timing path or entry points may import it
+    (bench.py's cpu_baseline leg and __graft_entry__.smoke() are the two sanctioned callers)."""
+    import os
+    import re
+    from conftest import PKG, ROOT
+    pat = re.compile(r'^\s*(from|import)\s+oracle\b', re.M)
+    for base, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                text = open(os.path.join(base, f), errors='ignore').read()
+                assert not pat.search(text), os.path.join(base, f)
+    bench = open(os.path.join(ROOT, 'bench.py')).read()
+    uses = [m.start() for m in pat.finditer(bench)]
+    assert len(uses) == 1 and 'def cpu_baseline' in bench[:uses[0]] and bench.rfind('def ', 0, uses[0]) == bench.find('def cpu_baseline')
