@@ -14,8 +14,21 @@ from flash_attn.flash_attn_interface import (flash_attn_unpadded_kvpacked_func,
 _NEG = -10000.0  # additive mask value of the eager path (reference mha.py:212,219)
 
 
+_CU_CACHE = {}
+
+
 def _fixed_cu_seqlens(batch, seqlen, device):
-    return torch.arange(0, (batch + 1) * seqlen, seqlen, dtype=torch.int32, device=device)
+    """int32 [0, S, 2S, ...] for a fixed-length batch (reference mha.py:91-94 builds it on every call; every layer
+    of a forward asks for the same one, so it is kept: one tiny launch per shape instead of one per layer)."""
+    # inference-mode tensors cannot be saved for backward later: keep them apart
+    key = (batch, seqlen, str(device), torch.is_inference_mode_enabled())
+    cu = _CU_CACHE.get(key)
+    if cu is None:
+        if len(_CU_CACHE) > 64:
+            _CU_CACHE.clear()
+        cu = torch.arange(0, (batch + 1) * seqlen, seqlen, dtype=torch.int32, device=device)
+        _CU_CACHE[key] = cu
+    return cu
 
 
 class FlashSelfAttention(nn.Module):
