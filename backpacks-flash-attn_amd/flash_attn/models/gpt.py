@@ -17,6 +17,8 @@ from flash_attn.modules.embedding import GPT2Embeddings
 from flash_attn.modules.mha import MHA
 from flash_attn.modules.mlp import FusedDenseGeluDense, Mlp
 from flash_attn.ops.layer_norm import dropout_add_layer_norm
+from flash_attn.utils.pretrained import state_dict_from_pretrained
+from src.utils.hf_convert import gpt2_trunk_state_dict, remap_state_dict_gpt2
 
 
 def create_mixer_cls(config, layer_idx=None, process_group=None, device=None, dtype=None):
@@ -91,6 +93,23 @@ class GPTPreTrainedModel(nn.Module):
         if not isinstance(config, GPT2Config):
             raise ValueError('config must be a transformers.GPT2Config, got %r' % type(config))
         self.config = config
+
+    @classmethod
+    def from_pretrained(cls, model_name, config, *inputs, state_dict=None, **kwargs):
+        """Build the model and load Hugging Face GPT-2 weights into it (reference gpt.py:140-151).
+        `state_dict`: an already loaded HF state dict (skips the lookup of `model_name`).  A `GPTLMHeadModel`
+        takes the remapped dict as it is; a bare `GPTModel` takes it without the `transformer.` prefix and
+        the head (upstream's strict load only works for the former)."""
+        model = cls(config, *inputs, **kwargs)
+        hf = state_dict if state_dict is not None else state_dict_from_pretrained(model_name)
+        if hasattr(model, 'lm_head'):
+            hf = {(k[len('transformer.'):] if k.startswith('transformer.') else k): v for k, v in hf.items()
+                  if k != 'lm_head.weight'}
+            model.load_state_dict(remap_state_dict_gpt2(hf, config))
+            model.tie_weights()
+        else:
+            model.load_state_dict(gpt2_trunk_state_dict(hf, config))
+        return model
 
 
 class GPTModel(GPTPreTrainedModel):

@@ -29,7 +29,9 @@ from flash_attn.models.gpt import GPTModel, GPTPreTrainedModel, _activation, _in
 from flash_attn.modules.block import Block
 from flash_attn.modules.mlp import FusedDenseGeluDense, Mlp
 from flash_attn.ops.layer_norm import dropout_add_layer_norm
+from flash_attn.utils.pretrained import state_dict_from_pretrained
 from src.utils.generation import GenerationMixin
+from src.utils.hf_convert import gpt2_trunk_state_dict, remap_state_dict_gpt2  # noqa: F401  (re-exported, reference :354)
 
 
 class BackpackConfig(GPT2Config):
@@ -116,6 +118,25 @@ class BackpackPreTrainedModel(nn.Module):
             raise ValueError('config must be a BackpackConfig, got %r' % type(config))
         self.config = config
 
+    @classmethod
+    def from_pretrained(cls, model_name, config, *inputs, state_dict=None, **kwargs):
+        """Build the model and initialise its GPT-2 TRUNK from Hugging Face GPT-2 weights; the content
+        model and the sense attention keep their fresh initialisation (reference :172-183).  Upstream hands
+        the `transformer.`-prefixed remapped dict to `model.gpt2_model`, whose keys carry no such prefix (and
+        which only `BackpackModel` has), so its strict load cannot succeed as written; here the prefix and
+        the LM head are dropped first and `BackpackLMHeadModel` is handled too (trunk = transformer.gpt2_model,
+        whose word embedding is the tied head)."""
+        return _load_gpt2_trunk(cls(config, *inputs, **kwargs), model_name, config, state_dict)
+
+
+def _load_gpt2_trunk(model, model_name, config, state_dict=None):
+    hf = state_dict if state_dict is not None else state_dict_from_pretrained(model_name)
+    trunk = model.gpt2_model if hasattr(model, 'gpt2_model') else model.transformer.gpt2_model
+    trunk.load_state_dict(gpt2_trunk_state_dict(hf, config))
+    if hasattr(model, 'tie_weights'):
+        model.tie_weights()
+    return model
+
 
 class BackpackContentModule(nn.Module):
     """Sense vectors C(x): word embedding (no positions) -> LN -> one no-mix block -> final MLP
@@ -175,6 +196,11 @@ class BackpackModel(GPTPreTrainedModel):
         self.embeddings = self.gpt2_model.embeddings   # shared with the contextualisation model
         self.contextualization_attn = ContextSelfAttn(self.num_content_vectors, config.n_embd,
                                                       use_hip=self.use_hip, **factory_kwargs)
+
+    @classmethod
+    def from_pretrained(cls, model_name, config, *inputs, state_dict=None, **kwargs):
+        """HF GPT-2 weights into the trunk only (see BackpackPreTrainedModel.from_pretrained)."""
+        return _load_gpt2_trunk(cls(config, *inputs, **kwargs), model_name, config, state_dict)
 
     def forward(self, input_ids, position_ids=None, inference_params=None):
         contextl_hidden_states = self.gpt2_model(input_ids, position_ids=position_ids,

@@ -4,7 +4,12 @@ whole forward on the grown prefix (so every step exercises the HIP attention and
 Differences kept deliberately small: the result is a plain dataclass instead of the
 transformers `*DecoderOnlyOutput` classes (removed in transformers 5), and the appended token is
 `unsqueeze(1)` so batch sizes > 1 work (the reference's `unsqueeze(0)` in greedy_decode, :68, only
-concatenates for batch 1; identical result there)."""
+concatenates for batch 1; identical result there).
+
+Index contract kept bit for bit: the reference never appends the LAST token it picks (:64-72 -- `seqlen`
+starts at prompt + 1 and the loop appends only while `seqlen < max_length`), so `sequences` has
+max(prompt_len, max_length - 1) columns, not max_length as its docstring says; `scores` holds the first
+step's logits only (:59).  Same here."""
 from dataclasses import dataclass, field
 from typing import Optional, Tuple
 
@@ -28,20 +33,23 @@ class DecoderOnlyOutput:
 
 
 def _decode(input_ids, model, max_length, pick):
-    scores = []
+    """The reference's loop, statement for statement (:56-72 / :31-44)."""
+    seqlen_og = input_ids.shape[1]
     with torch.inference_mode():
-        while True:
+        logits = model(input_ids).logits[:, -1]
+        scores = [logits]                       # upstream records the first step's scores only (:59,:32)
+        next_token = pick(logits)
+        seqlen = seqlen_og + 1
+        while seqlen < max_length:
+            input_ids = torch.cat((input_ids, next_token.unsqueeze(1)), dim=1)
             logits = model(input_ids).logits[:, -1]
-            if not scores:
-                scores.append(logits)          # upstream records the first step's scores only (:59,:32)
-            if input_ids.shape[1] >= max_length:
-                break
-            input_ids = torch.cat((input_ids, pick(logits).unsqueeze(1)), dim=1)
+            next_token = pick(logits)           # the pick of the final iteration is dropped, as upstream
+            seqlen += 1
     return DecoderOnlyOutput(sequences=input_ids, scores=tuple(scores))
 
 
 def greedy_decode(input_ids, model, max_length):
-    """input_ids (batch, seq_len) -> sequences (batch, max_length): argmax continuation."""
+    """input_ids (batch, seq_len) -> sequences (batch, max_length - 1): argmax continuation."""
     return _decode(input_ids, model, max_length, lambda logits: torch.argmax(logits, dim=-1))
 
 

@@ -168,18 +168,94 @@ def test_generation_and_checkpoint_roundtrip(tmp_path):
     assert not res.missing_keys and not res.unexpected_keys
     assert set(remove_model_prefix(ckpt)) == set(model.state_dict())
     ids = torch.randint(0, 96, (1, 5), generator=torch.Generator().manual_seed(1))
-    seq = model.generate(ids, max_length=9)
+    seq = model.generate(ids, max_length=10)
+    # the reference returns max_length - 1 tokens: its last pick is never appended (generation.py:64-72)
     assert seq.shape == (1, 9) and torch.equal(seq[:, :5], ids)
-    assert torch.equal(other.generate(ids, max_length=9), seq)          # same weights, same greedy path
+    assert torch.equal(other.generate(ids, max_length=10), seq)         # same weights, same greedy path
     # each new token is the argmax of the full forward on the prefix (no cache, as upstream)
     with torch.no_grad():
         for t in range(5, 9):
             assert seq[0, t] == model(seq[:, :t]).logits[0, -1].argmax()
     out = model.generate(ids, max_length=7, return_dict_in_generate=True, output_scores=True)
-    assert out.sequences.shape == (1, 7) and len(out.scores) == 1
-    assert model.sample(ids, max_length=8).shape == (1, 8)
-    batch = greedy_decode(torch.cat([ids, ids]), model, 8).sequences
+    assert out.sequences.shape == (1, 6) and len(out.scores) == 1
+    assert model.generate(ids, max_length=3).shape == (1, 5)           # nothing to add: the prompt comes back
+    assert model.sample(ids, max_length=8).shape == (1, 7)
+    batch = greedy_decode(torch.cat([ids, ids]), model, 9).sequences
     assert torch.equal(batch[0], batch[1]) and torch.equal(batch[0], seq[0, :8])
+
+
+def test_generation_matches_the_reference_token_for_token():
+    """G8 (tests/golden/make_golden_r2.py): the reference's own greedy_decode on the nano model -- same token
+    ids, same returned length (max_length - 1), same first-step scores."""
+    g4, g8 = load_golden('g4_nano_model.npz'), load_golden('g8_generation.npz')
+    sd = {k[3:]: torch.from_numpy(g4[k]) for k in g4.files if k.startswith('sd/')}
+    model = BackpackLMHeadModel(nano_config()).eval()
+    model.load_state_dict(sd)
+    prompt = torch.from_numpy(g8['prompt'])
+    for max_length in (6, 12, 20):
+        out = model.generate(prompt, max_length=max_length, return_dict_in_generate=True, output_scores=True)
+        want = torch.from_numpy(g8['greedy_%d' % max_length])
+        assert out.sequences.shape == want.shape == (1, max_length - 1)
+        assert torch.equal(out.sequences, want)
+        assert len(out.scores) == 1
+        assert (out.scores[0] - torch.from_numpy(g8['scores_%d' % max_length])).abs().max().item() < 1e-5
+    assert tuple(model.sample(prompt, max_length=12).shape) == tuple(g8['sample_12_shape'])
+
+
+def test_hf_gpt2_remap_matches_the_reference_and_transformers():
+    """G7: `remap_state_dict_gpt2` / `remap_state_dict_flash` against the outputs of the reference's functions
+    on the same tiny HF state dict (bit-exact: renames, transposes, zero padding), and `from_pretrained` end to
+    end: the flash-layout model on the remapped weights reproduces the logits of transformers' own
+    GPT2LMHeadModel (pins the LayerNorm half-block shift)."""
+    from transformers import GPT2Config
+    from flash_attn.models.gpt import GPTLMHeadModel, GPTModel
+    from src.models.backpack import remap_state_dict_gpt2
+    from src.utils.hf_convert import load_non_optimized_model, remap_state_dict_flash
+    g = load_golden('g7_hf_remap.npz')
+    hf = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('hf/')}
+    want_flash = {k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('flash/')}
+    want_back = {k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('back/')}
+    kw = dict(n_embd=int(g['n_embd']), n_head=int(g['n_head']), n_layer=int(g['n_layer']),
+              n_positions=int(g['n_positions']), resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0)
+    padded = GPT2Config(vocab_size=int(g['padded_vocab_size']), **kw)
+    flash = remap_state_dict_gpt2(hf, padded)
+    assert set(flash) == set(want_flash)
+    for k, v in want_flash.items():
+        assert torch.equal(flash[k], v), k
+    assert flash['lm_head.weight'] is flash['transformer.embeddings.word_embeddings.weight']
+    assert torch.count_nonzero(flash['lm_head.weight'][int(g['vocab_size']):]) == 0
+    back = remap_state_dict_flash(flash, padded)
+    assert set(back) == set(want_back)
+    for k, v in want_back.items():
+        assert torch.equal(back[k], v), k
+    assert 'wte.weight' in hf and 'h.0.attn.bias' in hf        # the caller's dict is left alone
+
+    cfg = GPT2Config(vocab_size=int(g['vocab_size']), **kw)
+    cfg.pad_vocab_size_multiple = 8
+    ids = torch.from_numpy(g['ids'])
+    model = GPTLMHeadModel.from_pretrained('unused', cfg, state_dict=hf).eval()
+    assert cfg.vocab_size == int(g['padded_vocab_size'])       # padded in place, as upstream (gpt.py:180-183)
+    with torch.no_grad():
+        logits = model(ids).logits
+    want = torch.from_numpy(g['hf_logits'])
+    assert (logits[..., :want.shape[-1]] - want).abs().max().item() < 1e-4
+    # GPT2LMHeadModel-style checkpoints (keys under `transformer.` + lm_head) load as well
+    prefixed = {('transformer.' + k): v for k, v in hf.items()}
+    prefixed['lm_head.weight'] = hf['wte.weight']
+    trunk = GPTModel.from_pretrained('unused', cfg, state_dict=prefixed).eval()
+    with torch.no_grad():
+        assert torch.equal(trunk(ids), model.transformer(ids))
+
+    # Backpack: the trunk takes the GPT-2 weights, the sense network keeps its initialisation
+    bcfg = BackpackConfig(vocab_size=int(g['vocab_size']), num_content_vectors=4, pad_vocab_size_multiple=8,
+                          use_flash_attn=True, fused_dropout_add_ln=True, **kw)
+    bp_model = BackpackLMHeadModel.from_pretrained('unused', bcfg, state_dict=hf)
+    assert torch.equal(bp_model.lm_head.weight, flash['lm_head.weight'])
+    assert bp_model.lm_head.weight is bp_model.transformer.content_model.embeddings.word_embeddings.weight
+    eager = load_non_optimized_model(bp_model).eval()          # every fused / flash switch off, same weights
+    assert not eager.config.use_flash_attn and not eager.config.fused_dropout_add_ln
+    with torch.no_grad():
+        assert torch.equal(eager.transformer.gpt2_model(ids), trunk(ids))
 
 
 def _g6():
