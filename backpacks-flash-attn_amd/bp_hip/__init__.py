@@ -148,12 +148,46 @@ def flash_bwd(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seql
     _flash_attn_backward (flash_attn/flash_attn_interface.py:31-47).  `out` and `softmax_lse` are
     the forward's results."""
     _require_cuda(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seqlens_k)
-    dout = dout.contiguous()
+    # the same checks as flash_fwd, plus the gradient buffers: a mismatched dk/dv or a wrong max_seqlen would
+    # otherwise be an out-of-bounds write inside the kernel (the reference checks these in mha_bwd,
+    # csrc/flash_attn/fmha_api.cpp:375-420)
+    if q.dim() != 3 or k.dim() != 3:
+        raise RuntimeError('bp_hip.flash_bwd: q, k, v must be (total, nheads, headdim)')
     total_q, nheads, d = q.shape
+    for name, t, like in (('k', k, None), ('v', v, k), ('out', out, q), ('dout', dout, q), ('dq', dq, q),
+                          ('dk', dk, k), ('dv', dv, k)):
+        if t.dtype != q.dtype:
+            raise RuntimeError(f'bp_hip.flash_bwd: {name} must have the dtype of q')
+        if like is not None and t.shape != like.shape:
+            raise RuntimeError(f'bp_hip.flash_bwd: {name} has shape {tuple(t.shape)}, expected {tuple(like.shape)}')
+    if k.shape[1] != nheads or k.shape[2] != d:
+        raise RuntimeError('bp_hip.flash_bwd: q/k shape mismatch')
+    for name, t in (('q', q), ('k', k), ('v', v), ('dq', dq), ('dk', dk), ('dv', dv)):
+        if t.stride(-1) != 1:
+            raise RuntimeError(f'bp_hip.flash_bwd: last dimension of {name} must be contiguous')
+    if dout.stride(-1) != 1:
+        dout = dout.contiguous()
     if cu_seqlens_q is not None:
+        if cu_seqlens_k is None:
+            raise RuntimeError('bp_hip.flash_bwd: cu_seqlens_q and cu_seqlens_k must be given together')
+        for cu in (cu_seqlens_q, cu_seqlens_k):
+            if cu.dtype != torch.int32 or not cu.is_contiguous():
+                raise RuntimeError('bp_hip.flash_bwd: cu_seqlens must be contiguous int32')
         batch = cu_seqlens_q.numel() - 1
+        if cu_seqlens_k.numel() - 1 != batch:
+            raise RuntimeError('bp_hip.flash_bwd: cu_seqlens_q / cu_seqlens_k length mismatch')
     else:
+        if cu_seqlens_k is not None:
+            raise RuntimeError('bp_hip.flash_bwd: cu_seqlens_q and cu_seqlens_k must be given together')
         batch = total_q // max_seqlen_q
+        if batch * max_seqlen_q != total_q or batch * max_seqlen_k != k.shape[0]:
+            raise RuntimeError('bp_hip.flash_bwd: fixed-length batch does not divide total rows')
+    if batch <= 0:
+        raise RuntimeError('bp_hip.flash_bwd: empty batch')
+    if softmax_lse.dtype != torch.float32 or not softmax_lse.is_contiguous() or \
+            softmax_lse.shape != (batch, nheads, round_up(max_seqlen_q, 16)):
+        raise RuntimeError('bp_hip.flash_bwd: softmax_lse must be the contiguous fp32 (batch, nheads, '
+                           'roundup(max_seqlen_q, 16)) tensor the forward returned')
     lse_len = softmax_lse.shape[-1]
     if out.stride(-1) != 1:
         out = out.contiguous()

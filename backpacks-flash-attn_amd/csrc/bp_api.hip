@@ -19,23 +19,34 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 inline bool scale_ok(float s) { return isfinite(s) && s > 0.f; }
 
-// A/B switches for measurements only: BP_FLASH_IMPL=staged / BP_MIX_IMPL=staged force the
-// register-staged kernels even for shapes the LDS-DMA ring kernels accept.
+// Measurement switches exist only in development builds (build_hip.py --variant NAME -- -DBP_DEV_BUILD):
+// the shipped library reads no environment variable.  BP_FLASH_IMPL=staged / BP_MIX_IMPL=staged force the
+// register-staged kernels for shapes the LDS-DMA ring kernels accept; BP_FLASH_PAIR=0 unpairs causal tiles;
+// BP_MIX_ORDER picks the sense-mix work order.
+#ifdef BP_DEV_BUILD
 inline bool env_is(const char *name, const char *value) {
     const char *e = getenv(name);
     return e != nullptr && strcmp(e, value) == 0;
 }
+inline bool dev_force_staged_flash() { static const bool v = env_is("BP_FLASH_IMPL", "staged"); return v; }
+inline bool dev_force_staged_mix() { static const bool v = env_is("BP_MIX_IMPL", "staged"); return v; }
+inline bool dev_flash_pair() { static const bool v = !env_is("BP_FLASH_PAIR", "0"); return v; }
+inline int dev_mix_order() {
+    static const int v = env_is("BP_MIX_ORDER", "grouped") ? 0 : env_is("BP_MIX_ORDER", "lockstep") ? 2
+                       : env_is("BP_MIX_ORDER", "hybrid") ? 3 : 1;
+    return v;
+}
+#else
+inline bool dev_force_staged_flash() { return false; }
+inline bool dev_force_staged_mix() { return false; }
+inline bool dev_flash_pair() { return true; }
+inline int dev_mix_order() { return 1; }
+#endif
 
 // 16-byte friendly shapes take the LDS-DMA ring kernel; anything else (odd head dims, unaligned
 // views) the register-staged kernel with its element-wise loader.
 inline hipError_t dispatch_flash(const bp::FlashParams &p, int dtype, bool vec, hipStream_t st) {
-    static const bool force_staged = env_is("BP_FLASH_IMPL", "staged");
-    static const bool use_dma2 = env_is("BP_FLASH_IMPL", "dma2");
-    if (vec && use_dma2) {
-        hipError_t e = bp::launch_flash_fwd_dma2(p, dtype, st);
-        if (e != hipErrorNotSupported) return e;
-    }
-    if (vec && !force_staged) return bp::launch_flash_fwd_dma(p, dtype, st);
+    if (vec && !dev_force_staged_flash()) return bp::launch_flash_fwd_dma(p, dtype, st);
     return bp::launch_flash_fwd(p, dtype, vec, st);
 }
 
@@ -89,7 +100,7 @@ int bp_flash_fwd(const void *q, const void *k, const void *v, void *out, float *
     p.max_sq = max_seqlen_q; p.max_sk = max_seqlen_k;
     p.n_qtiles = (max_seqlen_q + 127) / 128;
     p.causal = is_causal ? 1 : 0;
-    p.pair = (p.causal && p.n_qtiles > 1 && !env_is("BP_FLASH_PAIR", "0")) ? 1 : 0;
+    p.pair = (p.causal && p.n_qtiles > 1 && dev_flash_pair()) ? 1 : 0;
     p.scale_log2e = softmax_scale * bp::kLog2e;
 
     bool vec = (head_dim % 8 == 0) && aligned16(q) && aligned16(k) && mult8(q_row_stride) &&
@@ -97,7 +108,6 @@ int bp_flash_fwd(const void *q, const void *k, const void *v, void *out, float *
     if (v != nullptr)
         vec = vec && aligned16(v) && aligned16(out) && mult8(v_row_stride) && mult8(v_head_stride) &&
               mult8(o_row_stride) && mult8(o_head_stride);
-    if (const char *pe = getenv("BP_PROF_PTR")) p.prof = reinterpret_cast<unsigned long long *>(strtoull(pe, nullptr, 0));
     hipError_t e = dispatch_flash(p, dtype, vec, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
 }
@@ -150,7 +160,7 @@ static int sense_lse(const void *qk, float *lse_ws, int batch, int seqlen, int n
     p.max_sq = seqlen; p.max_sk = seqlen;
     p.n_qtiles = (seqlen + 127) / 128;
     p.causal = 1;
-    p.pair = (p.n_qtiles > 1 && !env_is("BP_FLASH_PAIR", "0")) ? 1 : 0;
+    p.pair = (p.n_qtiles > 1 && dev_flash_pair()) ? 1 : 0;
     p.scale_log2e = softmax_scale * bp::kLog2e;
     const bool vec = (d_k % 8 == 0) && aligned16(qp) && aligned16(kp) && mult8(qk_bs) && mult8(qk_rs) &&
                      mult8(qk_ss);
@@ -242,20 +252,16 @@ int bp_sense_mix_weighted(const void *qk, const void *content, const float *key_
     p.b = batch; p.s = seqlen; p.nsenses = nsenses; p.dk = d_k; p.dout = d_out;
     p.n_qtiles = (seqlen + 255) / 256;
     p.n_chunks = (d_out + 255) / 256;
-    // block -> (group, query tile) order, see sense_mix_dma.hip.  1 (default): heaviest tiles of all
-    // groups first; 2: whole (batch, chunk) groups per XCD in lockstep; 3: 2/3 of the groups in lockstep,
-    // the rest heaviest-first; 0: whole groups per XCD without chunk adjacency.  A/B switch for measurements.
-    p.order = env_is("BP_MIX_ORDER", "grouped") ? 0 : env_is("BP_MIX_ORDER", "lockstep") ? 2
-            : env_is("BP_MIX_ORDER", "hybrid") ? 3 : 1;
+    // block -> (group, query tile) order, see sense_mix_dma.hip: heaviest tiles of all groups first
+    p.order = dev_mix_order();
     p.scale_log2e = softmax_scale * bp::kLog2e;
     const bool vec_qk = (d_k % 8 == 0) && aligned16(p.q) && aligned16(p.k) && mult8(qk_batch_stride) &&
                         mult8(qk_row_stride) && mult8(qk_sense_stride);
     const bool vec_c = (d_out % 8 == 0) && aligned16(content) && aligned16(out) && mult8(c_batch_stride) &&
                        mult8(c_row_stride) && mult8(c_sense_stride) && mult8(o_batch_stride) &&
                        mult8(o_row_stride);
-    static const bool force_staged = env_is("BP_MIX_IMPL", "staged");
     hipError_t e;
-    if (vec_qk && vec_c && !force_staged) e = bp::launch_sense_mix_dma(p, dtype, st);
+    if (vec_qk && vec_c && !dev_force_staged_mix()) e = bp::launch_sense_mix_dma(p, dtype, st);
     else e = bp::launch_sense_mix(p, dtype, vec_qk, vec_c, st);
     return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
 }

@@ -21,7 +21,6 @@ struct FlashParams {
     int causal;
     int pair;                 // flash_fwd_dma: one workgroup takes query tiles t and n-1-t (causal load balance)
     float scale_log2e;        // softmax_scale * log2(e)
-    unsigned long long *prof; // BP_PROFILE_PHASES debug builds only (8 u64 per wave), else NULL
 };
 
 struct FlashBwdParams {
@@ -127,8 +126,6 @@ hipError_t launch_add_layer_norm_bwd(const LnBwdParams &p, int dtype, hipStream_
 hipError_t launch_flash_fwd(const FlashParams &p, int dtype, bool vec, hipStream_t stream);
 // LDS-DMA ring version; needs 16-byte friendly shapes (vec)
 hipError_t launch_flash_fwd_dma(const FlashParams &p, int dtype, hipStream_t stream);
-// same + two 32-query blocks per wave (head_dim <= 64, needs v); hipErrorNotSupported otherwise
-hipError_t launch_flash_fwd_dma2(const FlashParams &p, int dtype, hipStream_t stream);
 hipError_t launch_attn_probs(const ProbsParams &p, int dtype, bool vec, hipStream_t stream);
 hipError_t launch_sense_mix(const MixParams &p, int dtype, bool vec_qk, bool vec_c, hipStream_t stream);
 // LDS-DMA ring version; needs 16-byte friendly shapes (vec_qk && vec_c)

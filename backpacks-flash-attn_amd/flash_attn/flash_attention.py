@@ -29,8 +29,8 @@ class FlashAttention(nn.Module):
                                                       causal=causal), None
         batch, seqlen = qkv.shape[0], qkv.shape[1]
         if key_padding_mask is None:
-            cu = torch.arange(0, (batch + 1) * seqlen, seqlen, dtype=torch.int32, device=qkv.device)
-            out = flash_attn_unpadded_qkvpacked_func(qkv.flatten(0, 1), cu, seqlen, p_drop,
+            # cu_seqlens=None = fixed-length batch (the reference builds an arange, flash_attention.py:47-49)
+            out = flash_attn_unpadded_qkvpacked_func(qkv.flatten(0, 1), None, seqlen, p_drop,
                                                      softmax_scale=self.softmax_scale, causal=causal)
             return out.unflatten(0, (batch, seqlen)), None
         nheads, hd = qkv.shape[-2], qkv.shape[-1]

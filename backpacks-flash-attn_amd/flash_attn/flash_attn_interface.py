@@ -31,7 +31,7 @@ def _flash_attn_forward(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, 
                                    max_seqlen_k, softmax_scale, causal)
     S_dmask = None
     if return_softmax:
-        batch = cu_seqlens_q.numel() - 1
+        batch = cu_seqlens_q.numel() - 1 if cu_seqlens_q is not None else q.shape[0] // max_seqlen_q
         if q.shape[0] == batch * max_seqlen_q and k.shape[0] == batch * max_seqlen_k:
             qb = q.unflatten(0, (batch, max_seqlen_q))
             kb = k.unflatten(0, (batch, max_seqlen_k))
@@ -50,9 +50,12 @@ def _flash_attn_backward(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens
     return dq, dk, dv
 
 
-def _eager_varlen(q, k, v, cu_q, cu_k, softmax_scale, causal):
+def _eager_varlen(q, k, v, cu_q, cu_k, softmax_scale, causal, max_q=None, max_k=None):
     """Differentiable recomputation, used by backward() for head dims the HIP backward lacks."""
     outs = []
+    if cu_q is None:   # fixed-length batch
+        cu_q = torch.arange(0, q.shape[0] + 1, max_q)
+        cu_k = torch.arange(0, k.shape[0] + 1, max_k)
     cu_q, cu_k = cu_q.tolist(), cu_k.tolist()
     for b in range(len(cu_q) - 1):
         qb, kb, vb = q[cu_q[b]:cu_q[b + 1]], k[cu_k[b]:cu_k[b + 1]], v[cu_k[b]:cu_k[b + 1]]
@@ -90,7 +93,7 @@ class _FlashAttnFuncBase(torch.autograd.Function):
                                         ctx.max_k, 0.0, ctx.softmax_scale, ctx.causal)
         with torch.enable_grad():
             q_, k_, v_ = (t.detach().requires_grad_() for t in (q, k, v))
-            out = _eager_varlen(q_, k_, v_, cu_q, cu_k, ctx.softmax_scale, ctx.causal)
+            out = _eager_varlen(q_, k_, v_, cu_q, cu_k, ctx.softmax_scale, ctx.causal, ctx.max_q, ctx.max_k)
             return torch.autograd.grad(out, (q_, k_, v_), dout)
 
 
@@ -158,7 +161,8 @@ class FlashAttnFunc(_FlashAttnFuncBase):
 def flash_attn_unpadded_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p, softmax_scale=None,
                                        causal=False, return_attn_probs=False):
     """qkv (total, 3, nheads, headdim); cu_seqlens int32 (batch+1); returns out (total, nheads,
-    headdim) [, softmax_lse (batch, nheads, seqlen), probs].  Reference: :242-267."""
+    headdim) [, softmax_lse (batch, nheads, seqlen), probs].  Reference: :242-267.
+    Extension: cu_seqlens=None means a fixed-length batch of total // max_seqlen sequences (no index tensor)."""
     return FlashAttnQKVPackedFunc.apply(qkv, cu_seqlens, max_seqlen, dropout_p, softmax_scale,
                                         causal, return_attn_probs)
 

@@ -14,23 +14,6 @@ from flash_attn.flash_attn_interface import (flash_attn_unpadded_kvpacked_func,
 _NEG = -10000.0  # additive mask value of the eager path (reference mha.py:212,219)
 
 
-_CU_CACHE = {}
-
-
-def _fixed_cu_seqlens(batch, seqlen, device):
-    """int32 [0, S, 2S, ...] for a fixed-length batch (reference mha.py:91-94 builds it on every call; every layer
-    of a forward asks for the same one, so it is kept: one tiny launch per shape instead of one per layer)."""
-    # inference-mode tensors cannot be saved for backward later: keep them apart
-    key = (batch, seqlen, str(device), torch.is_inference_mode_enabled())
-    cu = _CU_CACHE.get(key)
-    if cu is None:
-        if len(_CU_CACHE) > 64:
-            _CU_CACHE.clear()
-        cu = torch.arange(0, (batch + 1) * seqlen, seqlen, dtype=torch.int32, device=device)
-        _CU_CACHE[key] = cu
-    return cu
-
-
 class FlashSelfAttention(nn.Module):
     """Fused softmax attention on packed qkv.  Reference: mha.py:34-100."""
 
@@ -55,9 +38,11 @@ class FlashSelfAttention(nn.Module):
             return flash_attn_unpadded_qkvpacked_func(qkv, cu_seqlens, max_seqlen, p_drop,
                                                       softmax_scale=self.softmax_scale, causal=causal)
         batch, seqlen = qkv.shape[0], qkv.shape[1]
+        # fixed-length batch: cu_seqlens=None tells the C ABI that sequence b occupies rows [b*S, (b+1)*S)
+        # (bp_flash_fwd / bp_flash_bwd, include/bp_hip.h) -- the reference builds an arange here on every
+        # call (mha.py:91-94); no tensor means nothing a captured HIP graph could be left pointing at
         out = flash_attn_unpadded_qkvpacked_func(
-            qkv.flatten(0, 1), _fixed_cu_seqlens(batch, seqlen, qkv.device), seqlen, p_drop,
-            softmax_scale=self.softmax_scale, causal=causal)
+            qkv.flatten(0, 1), None, seqlen, p_drop, softmax_scale=self.softmax_scale, causal=causal)
         return out.unflatten(0, (batch, seqlen))
 
 
@@ -89,8 +74,7 @@ class FlashCrossAttention(nn.Module):
         batch, sq, sk = q.shape[0], q.shape[1], kv.shape[1]
         assert kv.shape[0] == batch and kv.shape[3] == q.shape[2] and kv.shape[4] == q.shape[3]
         out = flash_attn_unpadded_kvpacked_func(
-            q.flatten(0, 1), kv.flatten(0, 1), _fixed_cu_seqlens(batch, sq, q.device),
-            _fixed_cu_seqlens(batch, sk, q.device), sq, sk, p_drop,
+            q.flatten(0, 1), kv.flatten(0, 1), None, None, sq, sk, p_drop,
             softmax_scale=self.softmax_scale, causal=causal)
         return out.unflatten(0, (batch, sq))
 

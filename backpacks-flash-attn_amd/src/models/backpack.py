@@ -93,14 +93,30 @@ class ContextSelfAttn(nn.Module):
         self.use_hip = use_hip
 
     def project(self, encoded):
+        """encoded (B,S,d) -> qk (B,S,2,k,d_k).  On the HIP path a d_k that is not a multiple of 8 (the Mini
+        k=64 ablation: d_k = 10, training/configs/experiment/owt/backpack-mini-flash-vecs-64.yaml) is widened
+        to the next multiple with ZERO columns: the LDS-DMA kernels move 16-byte chunks, zeros add nothing to
+        q.k, and padding the projection's rows (1.3 M weights) instead of its output (2.6 KB per token, three
+        consumers) leaves autograd and the state-dict keys untouched.  Pair it with `scale()`."""
         b, s, d = encoded.shape
         k = self.num_content_vectors
-        return self.Wqkv(encoded).reshape(b, s, 2, k, d // k)
+        dk = d // k
+        pad = (-dk) % 8 if self.use_hip else 0
+        if pad == 0:
+            return self.Wqkv(encoded).reshape(b, s, 2, k, dk)
+        w = F.pad(self.Wqkv.weight.view(2, k, dk, d), (0, 0, 0, pad)).view(2 * k * (dk + pad), d)
+        bias = F.pad(self.Wqkv.bias.view(2, k, dk), (0, pad)).view(-1)
+        return F.linear(encoded, w, bias).view(b, s, 2, k, dk + pad)
+
+    def scale(self):
+        """softmax scale of the TRUE sense width d/k (reference :117), whatever `project` padded to."""
+        d_k = self.Wqkv.in_features // self.num_content_vectors
+        return self.softmax_scale or 1.0 / math.sqrt(d_k)
 
     def forward(self, encoded):
         qk = self.project(encoded)
         if self.use_hip:
-            return bp_hip.sense_alpha_autograd(qk, self.softmax_scale)
+            return bp_hip.sense_alpha_autograd(qk, self.scale())
         seqlen = qk.shape[1]
         q, k = qk.unbind(dim=2)
         scale = self.softmax_scale or 1.0 / math.sqrt(q.shape[-1])
@@ -210,7 +226,7 @@ class BackpackModel(GPTPreTrainedModel):
             # fused: softmax_causal(q_l k_l^T) @ C_l summed over senses, alpha never stored
             qk = self.contextualization_attn.project(contextl_hidden_states)
             return bp_hip.sense_mix_autograd(qk, content.transpose(1, 2),
-                                             self.contextualization_attn.softmax_scale)
+                                             self.contextualization_attn.scale())
         contextualization = self.contextualization_attn(contextl_hidden_states)   # (B,k,S,S)
         return torch.sum(contextualization @ content, dim=1)                       # (B,S,d)
 

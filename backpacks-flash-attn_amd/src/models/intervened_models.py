@@ -67,7 +67,7 @@ class _Intervened(nn.Module, GenerationMixin):
         """sum_l (alpha_l * key_weight_l) @ content_l; content (B,k,S,d_out), key_weight (B,k,S) or None."""
         attn = t.contextualization_attn
         if t.use_hip:
-            return bp_hip.sense_mix(attn.project(hidden), content.transpose(1, 2), attn.softmax_scale,
+            return bp_hip.sense_mix(attn.project(hidden), content.transpose(1, 2), attn.scale(),
                                     key_weight=key_weight)
         alpha = attn(hidden)                                                      # (B,k,S,S)
         if key_weight is not None:

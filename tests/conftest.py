@@ -13,6 +13,10 @@ for p in (ROOT, PKG):
 
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
+# the CPU oracle on a many-core host: more than ~16 intra-op threads only adds synchronisation cost
+# (scripts/cpu_threads_probe.py: 256 threads ran the fp32 forward 50x slower than 16)
+torch.set_num_threads(min(16, os.cpu_count() or 1))
+
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')

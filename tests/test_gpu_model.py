@@ -228,6 +228,7 @@ def test_intervened_models_hip_vs_oracle():
     eager = eager.to(torch.bfloat16)
     cases = [('weighted_anneal', im.WeightedBackpackLMHeadModel, dict(anneal=True)),
              ('weighted_plain', im.WeightedBackpackLMHeadModel, dict(anneal=False)),
+             ('negative_anneal', im.NegativeWeightedBackpackLMHeadModel, dict(anneal=True)),
              ('negative_plain', im.NegativeWeightedBackpackLMHeadModel, dict(anneal=False))]
     with torch.no_grad():
         for name, cls, opt in cases:
