@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('BP_HIP_LIB') or os.path.join(_HERE, 'libbackpack_hip.so')  # env: A/B builds only
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -24,13 +24,18 @@ SIGNATURES = {
     'bp_strerror': (ctypes.c_char_p, [_i32]),
     'bp_abi_version': (_i32, []),
     'bp_flash_fwd': (_i32, [_ptr] * 7 + [_i32] * 5 + [_i64] * 9 + [_f32, _i32, _i32, _ptr]),
+    'bp_flash_fwd_dropout': (_i32, [_ptr] * 7 + [_i32] * 5 + [_i64] * 9 + [_f32, _i32, _i32, _f32, _ptr, _ptr]),
     'bp_flash_bwd': (_i32, [_ptr] * 12 + [_i32] * 5 + [_i64] * 17 + [_f32, _i32, _i32, _ptr]),
+    'bp_flash_bwd_dropout': (_i32, [_ptr] * 12 + [_i32] * 5 + [_i64] * 17 + [_f32, _i32, _i32, _f32, _ptr, _ptr]),
     'bp_attn_probs': (_i32, [_ptr] * 4 + [_i32] * 5 + [_i64] * 10 + [_f32, _i32, _i32, _ptr]),
+    'bp_attn_probs_dropout': (_i32, [_ptr] * 4 + [_i32] * 5 + [_i64] * 10 + [_f32, _i32, _i32, _f32, _ptr, _ptr]),
     'bp_sense_lse': (_i32, [_ptr] * 2 + [_i32] * 4 + [_i64] * 4 + [_f32, _i32, _ptr]),
     'bp_sense_alpha': (_i32, [_ptr] * 3 + [_i32] * 5 + [_i64] * 4 + [_f32, _i32, _ptr]),
     'bp_sense_mix': (_i32, [_ptr] * 4 + [_i32] * 6 + [_i64] * 9 + [_f32, _i32, _ptr]),
     'bp_sense_mix_weighted': (_i32, [_ptr] * 5 + [_i32] * 6 + [_i64] * 11 + [_f32, _i32, _ptr]),
     'bp_add_layer_norm': (_i32, [_ptr] * 6 + [_i64, _i32, _f32] + [_i32] * 4 + [_ptr]),
+    'bp_dropout_add_layer_norm': (_i32, [_ptr] * 7 + [_i64, _i32, _f32] + [_i32] * 5 + [_f32, _ptr, _ptr]),
+    'bp_dropout_add_layer_norm_bwd': (_i32, [_ptr] * 9 + [_i64, _i32, _f32] + [_i32] * 4 + [_f32, _ptr, _ptr]),
     'bp_softmax_bwd_causal': (_i32, [_ptr, _ptr, _i64, _i32, _f32, _i32, _ptr]),
     'bp_add_layer_norm_bwd': (_i32, [_ptr] * 9 + [_i64, _i32, _f32, _i32, _i32, _i32, _ptr]),
     'bp_xentropy_fwd': (_i32, [_ptr] * 4 + [_i64, _i32, _i64, _f32, _i32, _i32, _ptr]),
@@ -88,11 +93,36 @@ def round_up(x, m):
     return (x + m - 1) // m * m
 
 
+def new_rng_state(device):
+    """Two fresh int64 words {seed, offset} ON THE DEVICE, drawn from torch's CUDA generator (so
+    `torch.manual_seed` makes dropout reproducible) -- the role of the at::Generator philox state the reference
+    hands its kernels (csrc/flash_attn/fmha_api.cpp:314-320).  Staying on the device keeps the call free of host
+    synchronisation and legal inside HIP-graph capture; save the tensor to regenerate the mask in backward."""
+    return torch.randint(-2 ** 63, 2 ** 63 - 1, (2,), dtype=torch.int64, device=device)
+
+
+def _dropout_args(dropout_p, rng_state, device):
+    dropout_p = float(dropout_p)
+    if not 0.0 <= dropout_p < 1.0:
+        raise RuntimeError('bp_hip: dropout_p must be in [0, 1)')
+    if dropout_p == 0.0:
+        return 0.0, None, None
+    if rng_state is None:
+        rng_state = new_rng_state(device)
+    if rng_state.dtype != torch.int64 or rng_state.numel() != 2 or not rng_state.is_cuda \
+            or not rng_state.is_contiguous():
+        raise RuntimeError('bp_hip: rng_state must be a contiguous int64 tensor of 2 elements on the GPU')
+    return dropout_p, rng_state, rng_state.data_ptr()
+
+
 def flash_fwd(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, softmax_scale,
-              causal):
+              causal, dropout_p=0.0, rng_state=None):
     """q (total_q,H,D), k/v (total_k,H,D), out like q (written in place); returns
     softmax_lse (B,H,roundup(max_seqlen_q,16)) fp32.  cu_seqlens_* int32 (B+1) or both None for a
-    fixed-length batch whose size is total_q // max_seqlen_q."""
+    fixed-length batch whose size is total_q // max_seqlen_q.
+    dropout_p > 0: attention dropout inside the kernel from `rng_state` (new_rng_state; created when None --
+    pass your own to be able to hand the same state to flash_bwd / attn_probs)."""
+    dropout_p, rng_state, rng_ptr = _dropout_args(dropout_p, rng_state, q.device)
     _require_cuda(q, k, v, out, cu_seqlens_q, cu_seqlens_k)
     if q.dim() != 3 or k.dim() != 3:
         raise RuntimeError('bp_hip.flash_fwd: q, k, v must be (total, nheads, headdim)')
@@ -122,7 +152,7 @@ def flash_fwd(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen
     lse_len = round_up(max_seqlen_q, 16)
     lse = torch.empty((batch, nheads, lse_len), dtype=torch.float32, device=q.device)
     with torch.cuda.device(q.device):
-        code = lib().bp_flash_fwd(
+        code = lib().bp_flash_fwd_dropout(
             q.data_ptr(), k.data_ptr(), v.data_ptr() if v is not None else None,
             out.data_ptr() if out is not None else None, lse.data_ptr(),
             cu_seqlens_q.data_ptr() if cu_seqlens_q is not None else None,
@@ -131,8 +161,8 @@ def flash_fwd(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen
             q.stride(0), q.stride(1), k.stride(0), k.stride(1),
             v.stride(0) if v is not None else 0, v.stride(1) if v is not None else 0,
             out.stride(0) if out is not None else 0, out.stride(1) if out is not None else 0,
-            lse_len, float(softmax_scale), int(bool(causal)), _dtype_code(q), _stream())
-    _check(code, 'bp_flash_fwd')
+            lse_len, float(softmax_scale), int(bool(causal)), _dtype_code(q), dropout_p, rng_ptr, _stream())
+    _check(code, 'bp_flash_fwd_dropout')
     return lse
 
 
@@ -143,10 +173,13 @@ def flash_bwd_supported(q):
 
 
 def flash_bwd(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seqlens_k, max_seqlen_q,
-              max_seqlen_k, softmax_scale, causal):
+              max_seqlen_k, softmax_scale, causal, dropout_p=0.0, rng_state=None):
     """dq, dk, dv (written in place) of the fused attention; arguments as the reference's
     _flash_attn_backward (flash_attn/flash_attn_interface.py:31-47).  `out` and `softmax_lse` are
-    the forward's results."""
+    the forward's results; with dropout, (dropout_p, rng_state) must be the forward's."""
+    if float(dropout_p) > 0.0 and rng_state is None:
+        raise RuntimeError('bp_hip.flash_bwd: dropout_p > 0 needs the rng_state the forward used')
+    dropout_p, rng_state, rng_ptr = _dropout_args(dropout_p, rng_state, q.device)
     _require_cuda(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seqlens_k)
     # the same checks as flash_fwd, plus the gradient buffers: a mismatched dk/dv or a wrong max_seqlen would
     # otherwise be an out-of-bounds write inside the kernel (the reference checks these in mha_bwd,
@@ -194,7 +227,7 @@ def flash_bwd(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seql
     # workspace for D_i = sum_d dO_i[d] * O_i[d] (filled by the dQ kernel, read by the dK/dV kernel)
     dsum = torch.empty((batch, nheads, lse_len), dtype=torch.float32, device=q.device)
     with torch.cuda.device(q.device):
-        code = lib().bp_flash_bwd(
+        code = lib().bp_flash_bwd_dropout(
             dout.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
             softmax_lse.data_ptr(), dsum.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
             cu_seqlens_q.data_ptr() if cu_seqlens_q is not None else None,
@@ -203,27 +236,31 @@ def flash_bwd(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seql
             dout.stride(0), dout.stride(1), q.stride(0), q.stride(1), k.stride(0), k.stride(1),
             v.stride(0), v.stride(1), out.stride(0), out.stride(1), dq.stride(0), dq.stride(1),
             dk.stride(0), dk.stride(1), dv.stride(0), dv.stride(1), lse_len, float(softmax_scale),
-            int(bool(causal)), _dtype_code(q), _stream())
-    _check(code, 'bp_flash_bwd')
+            int(bool(causal)), _dtype_code(q), dropout_p, rng_ptr, _stream())
+    _check(code, 'bp_flash_bwd_dropout')
     return dq, dk, dv
 
 
-def attn_probs(q, k, lse, softmax_scale, causal):
+def attn_probs(q, k, lse, softmax_scale, causal, dropout_p=0.0, rng_state=None):
     """q (B,Sq,H,D), k (B,Sk,H,D) (any batch/row/head strides), lse (B,H,>=Sq) fp32 ->
-    probabilities (B,H,Sq,Sk) in q's dtype."""
+    probabilities (B,H,Sq,Sk) in q's dtype.  With (dropout_p, rng_state) of a flash_fwd call: entries that
+    call dropped carry a set SIGN BIT (decode with torch.signbit; kept / dropped magnitudes are the undropped P)."""
     _require_cuda(q, k, lse)
+    if float(dropout_p) > 0.0 and rng_state is None:
+        raise RuntimeError('bp_hip.attn_probs: dropout_p > 0 needs the rng_state of the forward call')
+    dropout_p, rng_state, rng_ptr = _dropout_args(dropout_p, rng_state, q.device)
     b, sq, h, d = q.shape
     sk = k.shape[1]
     if q.stride(-1) != 1 or k.stride(-1) != 1 or not lse.is_contiguous():
         raise RuntimeError('bp_hip.attn_probs: bad strides')
     probs = torch.empty((b, h, sq, sk), dtype=q.dtype, device=q.device)
     with torch.cuda.device(q.device):
-        code = lib().bp_attn_probs(
+        code = lib().bp_attn_probs_dropout(
             q.data_ptr(), k.data_ptr(), lse.data_ptr(), probs.data_ptr(), b, h, d, sq, sk,
             q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
             lse.shape[-1], probs.stride(0), probs.stride(1), probs.stride(2),
-            float(softmax_scale), int(bool(causal)), _dtype_code(q), _stream())
-    _check(code, 'bp_attn_probs')
+            float(softmax_scale), int(bool(causal)), _dtype_code(q), dropout_p, rng_ptr, _stream())
+    _check(code, 'bp_attn_probs_dropout')
     return probs
 
 
@@ -328,20 +365,35 @@ def sense_mix(qk, content, softmax_scale=None, out=None, lse=None, key_weight=No
     return out
 
 
-def add_layer_norm(x0, x1, weight, bias, eps, residual_dtype=None, return_residual=True):
-    """Fused z = LayerNorm(x0 + x1) (fp32 math) and the updated residual stream x = x0 + x1.
+def _ln_16bit_code(*tensors):
+    """dtype code of the 16-bit type in play (x0 / residual / weights may each be 16-bit or fp32)."""
+    for t in tensors:
+        if t is not None and t.dtype in (torch.float16, torch.bfloat16):
+            return _dtype_code(t), t.dtype
+    return 1, torch.bfloat16
 
-    x0 (..., cols) fp16/bf16 contiguous; x1 same shape (fp32 or x0's dtype) or None; weight/bias
-    (cols,) fp32 or x0's dtype.  Returns (z in x0's dtype, x in residual_dtype) -- or z alone.
-    residual_dtype defaults to x1's dtype (reference rule, csrc/layer_norm/ln_api.cpp:99-102).
-    Replaces dropout_add_layer_norm with dropout_p = 0 (flash_attn/ops/layer_norm.py:207-217)."""
+
+def add_layer_norm(x0, x1, weight, bias, eps, residual_dtype=None, return_residual=True, dropout_p=0.0,
+                   rng_state=None, return_dropout_mask=False):
+    """Fused z = LayerNorm(dropout(x0) / (1 - p) + x1) (fp32 math) and the updated residual stream
+    x = dropout(x0) / (1 - p) + x1.
+
+    x0 (..., cols) fp16 / bf16 / fp32 contiguous; x1 same shape (fp32 or x0's dtype) or None; weight/bias
+    (cols,) fp32 or 16-bit.  Returns (z in x0's dtype, x in residual_dtype) -- or z alone -- and, when asked,
+    the uint8 keep mask (all ones without dropout).  residual_dtype defaults to x1's dtype (reference rule,
+    csrc/layer_norm/ln_api.cpp:99-102).  Replaces dropout_add_layer_norm (flash_attn/ops/layer_norm.py:207-217).
+    dropout_p > 0 draws from `rng_state` (new_rng_state; pass your own to hand the same state to
+    add_layer_norm_bwd)."""
     _require_cuda(x0, x1, weight, bias)
-    code_dt = _dtype_code(x0)
+    if x0.dtype not in (torch.float16, torch.bfloat16, torch.float32):
+        raise RuntimeError(f'bp_hip.add_layer_norm: x0 must be fp16, bf16 or fp32, got {x0.dtype}')
     cols = x0.shape[-1]
     if weight.shape != (cols,) or bias.shape != (cols,) or weight.dtype != bias.dtype:
         raise RuntimeError('bp_hip.add_layer_norm: weight/bias must be (cols,) of one dtype')
-    if weight.dtype not in (torch.float32, x0.dtype):
-        raise RuntimeError('bp_hip.add_layer_norm: weight dtype must be fp32 or the input dtype')
+    code_dt, dt16 = _ln_16bit_code(x0, x1, weight)
+    x0_f32 = x0.dtype == torch.float32
+    if weight.dtype not in (torch.float32, dt16):
+        raise RuntimeError('bp_hip.add_layer_norm: weight dtype must be fp32 or the 16-bit dtype in use')
     x0c = x0.contiguous()
     x1c = None
     if x1 is not None:
@@ -352,18 +404,27 @@ def add_layer_norm(x0, x1, weight, bias, eps, residual_dtype=None, return_residu
         residual_dtype = x1.dtype if x1 is not None else x0.dtype
     if residual_dtype not in (torch.float32, x0.dtype):
         raise RuntimeError('bp_hip.add_layer_norm: residual dtype must be fp32 or the input dtype')
+    dropout_p, rng_state, rng_ptr = _dropout_args(dropout_p, rng_state, x0.device)
     z = torch.empty_like(x0c)
     xo = torch.empty(x0c.shape, dtype=residual_dtype, device=x0.device) if return_residual else None
+    dmask = None
+    if return_dropout_mask:
+        dmask = (torch.empty(x0c.shape, dtype=torch.uint8, device=x0.device) if dropout_p > 0.0
+                 else torch.ones(x0c.shape, dtype=torch.uint8, device=x0.device))
     rows = x0c.numel() // cols
     wc, bc = weight.contiguous(), bias.contiguous()
     with torch.cuda.device(x0.device):
-        code = lib().bp_add_layer_norm(
+        code = lib().bp_dropout_add_layer_norm(
             x0c.data_ptr(), x1c.data_ptr() if x1c is not None else None, wc.data_ptr(), bc.data_ptr(),
-            z.data_ptr(), xo.data_ptr() if xo is not None else None, rows, cols, float(eps), code_dt,
-            int(x1c is not None and x1c.dtype == torch.float32), int(residual_dtype == torch.float32),
-            int(weight.dtype == torch.float32), _stream())
-    _check(code, 'bp_add_layer_norm')
-    return (z, xo) if return_residual else z
+            z.data_ptr(), xo.data_ptr() if xo is not None else None,
+            dmask.data_ptr() if (dmask is not None and dropout_p > 0.0) else None, rows, cols, float(eps), code_dt,
+            int(x0_f32), int(x1c is not None and x1c.dtype == torch.float32), int(residual_dtype == torch.float32),
+            int(weight.dtype == torch.float32), dropout_p, rng_ptr, _stream())
+    _check(code, 'bp_dropout_add_layer_norm')
+    outs = (z, xo) if return_residual else (z,)
+    if return_dropout_mask:
+        outs = outs + (dmask,)
+    return outs if len(outs) > 1 else outs[0]
 
 
 def softmax_bwd_causal_supported(alpha):
@@ -476,13 +537,14 @@ LN_BWD_WS_ROWS = 1024
 
 
 def add_layer_norm_bwd_supported(x0_dtype, cols):
-    return x0_dtype in (torch.float16, torch.bfloat16) and cols % 4 == 0 and cols <= 2048
+    return x0_dtype in (torch.float16, torch.bfloat16, torch.float32) and cols % 4 == 0 and cols <= 2048
 
 
-def add_layer_norm_bwd(dz, dx_in, x, weight, eps, want_dx1):
+def add_layer_norm_bwd(dz, dx_in, x, weight, eps, want_dx1, dropout_p=0.0, rng_state=None):
     """Backward of add_layer_norm: (dx0 in dz's dtype, dx1 in x's dtype or None, dweight, dbias).
-    dz (..., cols) 16-bit; dx_in gradient of the residual output (x's dtype) or None; x the summed stream
-    the forward normalised (fp32 or dz's dtype).  Replaces dropout_add_ln_bwd with dropout_p = 0
+    dz (..., cols) in the forward's x0 / z dtype; dx_in gradient of the residual output (x's dtype) or None; x
+    the summed stream the forward normalised (fp32 or dz's dtype).  With dropout, (dropout_p, rng_state) are the
+    forward's: dx0 passes the regenerated mask and the 1 / (1 - p) scale.  Replaces dropout_add_ln_bwd
     (flash_attn/ops/layer_norm.py:47-76)."""
     _require_cuda(dz, dx_in, x, weight)
     cols = dz.shape[-1]
@@ -490,18 +552,22 @@ def add_layer_norm_bwd(dz, dx_in, x, weight, eps, want_dx1):
     dxc = dx_in.contiguous() if dx_in is not None else None
     if xc.dtype not in (torch.float32, dzc.dtype) or (dxc is not None and dxc.dtype != xc.dtype):
         raise RuntimeError('bp_hip.add_layer_norm_bwd: x / dx_in must be fp32 or dz\'s dtype, and agree')
+    if float(dropout_p) > 0.0 and rng_state is None:
+        raise RuntimeError('bp_hip.add_layer_norm_bwd: dropout_p > 0 needs the rng_state the forward used')
+    dropout_p, rng_state, rng_ptr = _dropout_args(dropout_p, rng_state, dz.device)
+    code_dt, _ = _ln_16bit_code(dzc, xc, weight)
     rows = dzc.numel() // cols
     dx0 = torch.empty_like(dzc)
     dx1 = torch.empty_like(xc) if want_dx1 else None
     dw, db = torch.empty_like(weight), torch.empty_like(weight)
     ws = torch.empty((2, LN_BWD_WS_ROWS, cols), dtype=torch.float32, device=dz.device)
     with torch.cuda.device(dz.device):
-        code = lib().bp_add_layer_norm_bwd(
+        code = lib().bp_dropout_add_layer_norm_bwd(
             dzc.data_ptr(), dxc.data_ptr() if dxc is not None else None, xc.data_ptr(), weight.data_ptr(),
             dx0.data_ptr(), dx1.data_ptr() if dx1 is not None else None, dw.data_ptr(), db.data_ptr(),
-            ws.data_ptr(), rows, cols, float(eps), _dtype_code(dzc), int(xc.dtype == torch.float32),
-            int(weight.dtype == torch.float32), _stream())
-    _check(code, 'bp_add_layer_norm_bwd')
+            ws.data_ptr(), rows, cols, float(eps), code_dt, int(dzc.dtype == torch.float32),
+            int(xc.dtype == torch.float32), int(weight.dtype == torch.float32), dropout_p, rng_ptr, _stream())
+    _check(code, 'bp_dropout_add_layer_norm_bwd')
     return dx0, dx1, dw, db
 
 

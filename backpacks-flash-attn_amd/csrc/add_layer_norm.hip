@@ -1,9 +1,15 @@
-// Fused residual-add + LayerNorm forward for gfx950 (eval path of the reference's
-// dropout_add_layer_norm: flash_attn/ops/layer_norm.py:102-230, csrc/layer_norm/ln_api.cpp:83-254,
-// ln_fwd_kernels.cuh:20-162 -- with dropout_p = 0, no rowscale / colscale / subset):
+// Fused dropout + residual-add + LayerNorm forward for gfx950 (the reference's dropout_add_layer_norm:
+// flash_attn/ops/layer_norm.py:102-230, csrc/layer_norm/ln_api.cpp:83-254, ln_fwd_kernels.cuh:20-162 -- no
+// rowscale / colscale / subset):
 //
-//     x  = x0 + x1                 (x1 optional; x stored in the residual dtype, usually fp32)
+//     x  = dropout(x0) / (1 - p) + x1     (x1 optional; x stored in the residual dtype, usually fp32)
 //     z  = (x - mean(x)) * rsqrt(var(x) + eps) * gamma + beta      (fp32 math, stored in x0's dtype)
+//
+// x0 may be 16-bit or fp32 (under AMP the embedding output that enters the first LayerNorm is fp32 while the
+// blocks' outputs are 16-bit; the reference's otype = itype rule, ln_api.cpp:104).  Dropout bits: bp_philox.h, one
+// stream per call, counter (row, column / 4) -- the unit a lane owns; the backward regenerates them from the same
+// two generator words instead of reading a mask back (the optional `dmask` output exists for callers that ask
+// for it, layer_norm.py:207 return_dropout_mask).
 //
 // This is the memory-bound step on either side of every attention / MLP call:
 // unfused it is three torch kernels (add -> cast -> LayerNorm) moving 15 KB per 768-wide row, fused it
@@ -13,6 +19,7 @@
 // reduces across the wave with xor-shuffles.
 #include "bp_common.h"
 #include "bp_kernels.h"
+#include "bp_philox.h"
 
 namespace bp {
 
@@ -55,6 +62,9 @@ __global__ __launch_bounds__(256) void add_layer_norm_kernel(const LnParams p) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.rows) return;
     const int64_t base = row * p.cols;
+    const bool drop = p.drop_thr != 0u;
+    DropoutStream rng = {0u, 0u};
+    if (drop) rng = dropout_stream(p.rng_state, 0u);
 
     float x[CH][4];
     float sum = 0.f;
@@ -64,7 +74,19 @@ __global__ __launch_bounds__(256) void add_layer_norm_kernel(const LnParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) x[c][i] = 0.f;
         if (col < p.cols) {
-            load4<ET, false>(p.x0, base + col, x[c]);
+            if (p.x0_f32) load4<ET, true>(p.x0, base + col, x[c]);
+            else load4<ET, false>(p.x0, base + col, x[c]);
+            if (drop) {
+                uint32_t lo, hi, m = 0u;
+                dropout_bits4(rng, (uint32_t)row, (uint32_t)(col >> 2), lo, hi);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool keep = dropout_u16(lo, hi, i) < p.drop_thr;
+                    x[c][i] = keep ? x[c][i] * p.drop_scale : 0.f;
+                    m |= (keep ? 1u : 0u) << (8 * i);
+                }
+                if (p.dmask != nullptr) *reinterpret_cast<uint32_t *>(p.dmask + base + col) = m;
+            }
             if (p.x1 != nullptr) {
                 float r[4];
                 load4<ET, RES_F32>(p.x1, base + col, r);
@@ -104,7 +126,8 @@ __global__ __launch_bounds__(256) void add_layer_norm_kernel(const LnParams p) {
             load4<ET, W_F32>(p.beta, col, b);
 #pragma unroll
             for (int i = 0; i < 4; ++i) z[i] = (x[c][i] - mu) * rs * g[i] + b[i];
-            store4<ET, false>(p.z, base + col, z);
+            if (p.x0_f32) store4<ET, true>(p.z, base + col, z);
+            else store4<ET, false>(p.z, base + col, z);
         }
     }
 }
@@ -160,6 +183,9 @@ __global__ __launch_bounds__(256) void add_layer_norm_bwd_kernel(const LnBwdPara
     __shared__ float fold[2][CH * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float inv_n = 1.f / (float)p.cols;
+    const bool drop = p.drop_thr != 0u;
+    DropoutStream rng = {0u, 0u};
+    if (drop) rng = dropout_stream(p.rng_state, 0u);
 
     float g[CH][4], dg[CH][4], db[CH][4];
 #pragma unroll
@@ -181,7 +207,8 @@ __global__ __launch_bounds__(256) void add_layer_norm_bwd_kernel(const LnBwdPara
             for (int i = 0; i < 4; ++i) { x[c][i] = 0.f; dy[c][i] = 0.f; }
             if (col < p.cols) {
                 load4<ET, RES_F32>(p.x, base + col, x[c]);
-                load4<ET, false>(p.dz, base + col, dy[c]);      // dz for now
+                if (p.x0_f32) load4<ET, true>(p.dz, base + col, dy[c]);      // dz for now (z has x0's dtype)
+                else load4<ET, false>(p.dz, base + col, dy[c]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) sum += x[c][i];
             }
@@ -234,8 +261,15 @@ __global__ __launch_bounds__(256) void add_layer_norm_bwd_kernel(const LnBwdPara
 #pragma unroll
                     for (int i = 0; i < 4; ++i) dx[i] += r[i];
                 }
-                store4<ET, false>(p.dx0, base + col, dx);
                 if (p.dx1 != nullptr) store4<ET, RES_F32>(p.dx1, base + col, dx);
+                if (drop) {   // x0 entered through dropout: its gradient passes the same mask and scale
+                    uint32_t lo, hi;
+                    dropout_bits4(rng, (uint32_t)row, (uint32_t)(col >> 2), lo, hi);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dx[i] = dropout_u16(lo, hi, i) < p.drop_thr ? dx[i] * p.drop_scale : 0.f;
+                }
+                if (p.x0_f32) store4<ET, true>(p.dx0, base + col, dx);
+                else store4<ET, false>(p.dx0, base + col, dx);
             }
         }
     }

@@ -15,6 +15,7 @@
 // diagonal are not computed, only zero-filled with the same full-line stores.
 #include "bp_common.h"
 #include "bp_kernels.h"
+#include "bp_philox.h"
 
 namespace bp {
 
@@ -69,6 +70,14 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const ProbsParams p) {
         }
         qf[s] = v;
     }
+    // dropout report (bp_attn_probs_dropout): dropped entries get their sign bit set
+    const bool drop = p.drop_thr != 0u;
+    DropoutStream rng = {0u, 0u};
+    if (drop) rng = dropout_stream(p.rng_state, (uint32_t)bh);
+    auto keep_bits = [&](int kb, int kk) {
+        return drop ? dropout_keep_rowlane(rng, p.drop_thr, (uint32_t)my_q, (uint32_t)(kb * C::BN + kk * 32), hh)
+                    : 0xffffu;
+    };
     float lse2 = 0.f;
     if (my_q < p.sq) lse2 = p.lse[((int64_t)batch * p.h + head) * p.lse_stride + my_q] * kLog2e;
 
@@ -164,6 +173,7 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const ProbsParams p) {
                         const u32x4 a = lds_read_16B(kbuf, k_lane_off + kk * 32 * C::KROW + s * 32);
                         st = E::mfma(a, qf[s], st);
                     }
+                    const uint32_t keep = keep_bits(kb, kk);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         float e[4];
@@ -172,6 +182,7 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const ProbsParams p) {
                             const int key = kb * C::BN + kk * 32 + 8 * g + 4 * hh + i;
                             e[i] = fast_exp2(fmaf(st[4 * g + i], c2, -lse2));
                             if (p.causal && key > my_q) e[i] = 0.f;
+                            if (!((keep >> (4 * g + i)) & 1u)) e[i] = -e[i];
                         }
                         // my 4 keys = 8-byte unit (kk*8 + 2*g + hh) of row l31
                         const int unit = (kk * 8 + 2 * g + hh) ^ (l31 & 15);
@@ -199,11 +210,13 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const ProbsParams p) {
                         const u32x4 a = lds_read_16B(kbuf, k_lane_off + kk * 32 * C::KROW + s * 32);
                         st = E::mfma(a, qf[s], st);
                     }
+                    const uint32_t keep = keep_bits(kb, kk);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int key = kb * C::BN + kk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                         float e = fast_exp2(fmaf(st[r], c2, -lse2));
                         if (key >= p.sk || (p.causal && key > my_q)) e = 0.f;
+                        if (!((keep >> r) & 1u)) e = -e;
                         st[r] = e;
                     }
 #pragma unroll

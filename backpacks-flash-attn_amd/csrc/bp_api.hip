@@ -19,6 +19,19 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 inline bool scale_ok(float s) { return isfinite(s) && s > 0.f; }
 
+// dropout argument check shared by the *_dropout entry points: p in [0, 1), a generator state when p > 0.
+// thr: keep iff a 16-bit uniform < thr (bp_philox.h); 0 = dropout off.
+inline bool dropout_args(float p, const uint64_t *rng_state, uint32_t &thr, float &rp_keep) {
+    thr = 0u; rp_keep = 1.f;
+    if (!(p >= 0.f && p < 1.f)) return false;
+    if (p == 0.f) return true;
+    if (rng_state == nullptr) return false;
+    long t = lrintf((1.f - p) * 65536.f);
+    thr = (uint32_t)(t < 1 ? 1 : t > 65535 ? 65535 : t);
+    rp_keep = 1.f / (1.f - p);
+    return true;
+}
+
 // Measurement switches exist only in development builds (build_hip.py --variant NAME -- -DBP_DEV_BUILD):
 // the shipped library reads no environment variable.  BP_FLASH_IMPL=staged / BP_MIX_IMPL=staged force the
 // register-staged kernels for shapes the LDS-DMA ring kernels accept; BP_FLASH_PAIR=0 unpairs causal tiles;
@@ -63,6 +76,7 @@ const char *bp_strerror(int code) {
         case BP_ERR_SCALE: return "softmax_scale must be finite and > 0";
         case BP_ERR_LAUNCH: return "HIP kernel launch failed";
         case BP_ERR_DOUT: return "d_out must be >= 1";
+        case BP_ERR_DROPOUT: return "dropout: p must be in [0, 1), rng_state non-NULL when p > 0, 16-byte friendly shapes only";
         default: return "unknown error";
     }
 }
@@ -78,6 +92,21 @@ int bp_flash_fwd(const void *q, const void *k, const void *v, void *out, float *
                  int64_t o_row_stride, int64_t o_head_stride,
                  int64_t lse_stride, float softmax_scale, int is_causal, int dtype,
                  bp_stream_t stream) {
+    return bp_flash_fwd_dropout(q, k, v, out, softmax_lse, cu_seqlens_q, cu_seqlens_k, batch, nheads, head_dim,
+                                max_seqlen_q, max_seqlen_k, q_row_stride, q_head_stride, k_row_stride,
+                                k_head_stride, v_row_stride, v_head_stride, o_row_stride, o_head_stride,
+                                lse_stride, softmax_scale, is_causal, dtype, 0.f, nullptr, stream);
+}
+
+int bp_flash_fwd_dropout(const void *q, const void *k, const void *v, void *out, float *softmax_lse,
+                         const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k,
+                         int batch, int nheads, int head_dim, int max_seqlen_q, int max_seqlen_k,
+                         int64_t q_row_stride, int64_t q_head_stride,
+                         int64_t k_row_stride, int64_t k_head_stride,
+                         int64_t v_row_stride, int64_t v_head_stride,
+                         int64_t o_row_stride, int64_t o_head_stride,
+                         int64_t lse_stride, float softmax_scale, int is_causal, int dtype,
+                         float p_dropout, const uint64_t *rng_state, bp_stream_t stream) {
     if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
     if (head_dim < 1 || head_dim > 128) return BP_ERR_HEAD_DIM;
     if (batch <= 0 || nheads <= 0 || max_seqlen_q <= 0 || max_seqlen_k < 0) return BP_ERR_SHAPE;
@@ -102,12 +131,16 @@ int bp_flash_fwd(const void *q, const void *k, const void *v, void *out, float *
     p.causal = is_causal ? 1 : 0;
     p.pair = (p.causal && p.n_qtiles > 1 && dev_flash_pair()) ? 1 : 0;
     p.scale_log2e = softmax_scale * bp::kLog2e;
+    p.rng_state = rng_state;
+    if (!dropout_args(p_dropout, rng_state, p.drop_thr, p.drop_scale)) return BP_ERR_DROPOUT;
+    if (p.drop_thr != 0u && v == nullptr) return BP_ERR_DROPOUT;   // dropout acts on P V: nothing to drop in an LSE pass
 
     bool vec = (head_dim % 8 == 0) && aligned16(q) && aligned16(k) && mult8(q_row_stride) &&
                mult8(q_head_stride) && mult8(k_row_stride) && mult8(k_head_stride);
     if (v != nullptr)
         vec = vec && aligned16(v) && aligned16(out) && mult8(v_row_stride) && mult8(v_head_stride) &&
               mult8(o_row_stride) && mult8(o_head_stride);
+    if (p.drop_thr != 0u && !vec) return BP_ERR_DROPOUT;   // the element-wise loader path has no dropout
     hipError_t e = dispatch_flash(p, dtype, vec, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
 }
@@ -119,6 +152,20 @@ int bp_attn_probs(const void *q, const void *k, const float *softmax_lse, void *
                   int64_t lse_stride,
                   int64_t p_batch_stride, int64_t p_head_stride, int64_t p_row_stride,
                   float softmax_scale, int is_causal, int dtype, bp_stream_t stream) {
+    return bp_attn_probs_dropout(q, k, softmax_lse, probs, batch, nheads, head_dim, seqlen_q, seqlen_k,
+                                 q_batch_stride, q_row_stride, q_head_stride, k_batch_stride, k_row_stride,
+                                 k_head_stride, lse_stride, p_batch_stride, p_head_stride, p_row_stride,
+                                 softmax_scale, is_causal, dtype, 0.f, nullptr, stream);
+}
+
+int bp_attn_probs_dropout(const void *q, const void *k, const float *softmax_lse, void *probs,
+                          int batch, int nheads, int head_dim, int seqlen_q, int seqlen_k,
+                          int64_t q_batch_stride, int64_t q_row_stride, int64_t q_head_stride,
+                          int64_t k_batch_stride, int64_t k_row_stride, int64_t k_head_stride,
+                          int64_t lse_stride,
+                          int64_t p_batch_stride, int64_t p_head_stride, int64_t p_row_stride,
+                          float softmax_scale, int is_causal, int dtype,
+                          float p_dropout, const uint64_t *rng_state, bp_stream_t stream) {
     if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
     if (head_dim < 1 || head_dim > 128) return BP_ERR_HEAD_DIM;
     if (batch <= 0 || nheads <= 0 || seqlen_q <= 0 || seqlen_k <= 0) return BP_ERR_SHAPE;
@@ -137,6 +184,9 @@ int bp_attn_probs(const void *q, const void *k, const float *softmax_lse, void *
                (p_head_stride & 3) == 0 && (p_row_stride & 3) == 0) ? 1 : 0;
     p.p_vec16 = (aligned16(probs) && mult8(p_batch_stride) && mult8(p_head_stride) && mult8(p_row_stride)) ? 1 : 0;
     p.scale_log2e = softmax_scale * bp::kLog2e;
+    p.rng_state = rng_state;
+    float unused_scale;
+    if (!dropout_args(p_dropout, rng_state, p.drop_thr, unused_scale)) return BP_ERR_DROPOUT;
     const bool vec = (head_dim % 8 == 0) && aligned16(q) && aligned16(k) && mult8(q_batch_stride) &&
                      mult8(q_row_stride) && mult8(q_head_stride) && mult8(k_batch_stride) &&
                      mult8(k_row_stride) && mult8(k_head_stride);
@@ -280,6 +330,28 @@ int bp_flash_bwd(const void *dout, const void *q, const void *k, const void *v, 
                  int64_t dv_row_stride, int64_t dv_head_stride,
                  int64_t lse_stride, float softmax_scale, int is_causal, int dtype,
                  bp_stream_t stream) {
+    return bp_flash_bwd_dropout(dout, q, k, v, out, softmax_lse, dsum_ws, dq, dk, dv, cu_seqlens_q, cu_seqlens_k, batch,
+                                nheads, head_dim, max_seqlen_q, max_seqlen_k, do_row_stride, do_head_stride,
+                                q_row_stride, q_head_stride, k_row_stride, k_head_stride, v_row_stride,
+                                v_head_stride, o_row_stride, o_head_stride, dq_row_stride, dq_head_stride,
+                                dk_row_stride, dk_head_stride, dv_row_stride, dv_head_stride, lse_stride,
+                                softmax_scale, is_causal, dtype, 0.f, nullptr, stream);
+}
+
+int bp_flash_bwd_dropout(const void *dout, const void *q, const void *k, const void *v, const void *out,
+                 const float *softmax_lse, float *dsum_ws, void *dq, void *dk, void *dv,
+                 const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k,
+                 int batch, int nheads, int head_dim, int max_seqlen_q, int max_seqlen_k,
+                 int64_t do_row_stride, int64_t do_head_stride,
+                 int64_t q_row_stride, int64_t q_head_stride,
+                 int64_t k_row_stride, int64_t k_head_stride,
+                 int64_t v_row_stride, int64_t v_head_stride,
+                 int64_t o_row_stride, int64_t o_head_stride,
+                 int64_t dq_row_stride, int64_t dq_head_stride,
+                 int64_t dk_row_stride, int64_t dk_head_stride,
+                 int64_t dv_row_stride, int64_t dv_head_stride,
+                 int64_t lse_stride, float softmax_scale, int is_causal, int dtype,
+                 float p_dropout, const uint64_t *rng_state, bp_stream_t stream) {
     if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
     if (head_dim < 8 || head_dim > 128 || head_dim % 8 != 0) return BP_ERR_HEAD_DIM;
     if (batch <= 0 || nheads <= 0 || max_seqlen_q <= 0 || max_seqlen_k <= 0) return BP_ERR_SHAPE;
@@ -306,6 +378,8 @@ int bp_flash_bwd(const void *dout, const void *q, const void *k, const void *v, 
     p.b = batch; p.h = nheads; p.d = head_dim; p.max_sq = max_seqlen_q; p.max_sk = max_seqlen_k;
     p.causal = is_causal ? 1 : 0;
     p.scale = softmax_scale;
+    p.rng_state = rng_state;
+    if (!dropout_args(p_dropout, rng_state, p.drop_thr, p.drop_scale)) return BP_ERR_DROPOUT;
     hipError_t e = bp::launch_flash_bwd(p, dtype, static_cast<hipStream_t>(stream));
     if (e == hipErrorNotSupported) return BP_ERR_HEAD_DIM;
     return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
@@ -314,19 +388,33 @@ int bp_flash_bwd(const void *dout, const void *q, const void *k, const void *v, 
 int bp_add_layer_norm(const void *x0, const void *x1, const void *gamma, const void *beta, void *z,
                       void *x_out, int64_t rows, int cols, float epsilon, int dtype, int x1_is_f32,
                       int xout_is_f32, int w_is_f32, bp_stream_t stream) {
+    return bp_dropout_add_layer_norm(x0, x1, gamma, beta, z, x_out, nullptr, rows, cols, epsilon, dtype, 0,
+                                     x1_is_f32, xout_is_f32, w_is_f32, 0.f, nullptr, stream);
+}
+
+int bp_dropout_add_layer_norm(const void *x0, const void *x1, const void *gamma, const void *beta, void *z,
+                              void *x_out, uint8_t *dmask, int64_t rows, int cols, float epsilon, int dtype,
+                              int x0_is_f32, int x1_is_f32, int xout_is_f32, int w_is_f32,
+                              float p_dropout, const uint64_t *rng_state, bp_stream_t stream) {
     if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
-    if (rows <= 0 || cols <= 0 || cols % 4 != 0 || cols > 8192) return BP_ERR_SHAPE;
+    if (rows <= 0 || rows > 0xffffffffLL || cols <= 0 || cols % 4 != 0 || cols > 8192) return BP_ERR_SHAPE;
     if (x0 == nullptr || gamma == nullptr || beta == nullptr || z == nullptr) return BP_ERR_SHAPE;
     if (!aligned16(x0) || !aligned16(gamma) || !aligned16(beta) || !aligned16(z) ||
-        (x1 != nullptr && !aligned16(x1)) || (x_out != nullptr && !aligned16(x_out)))
+        (x1 != nullptr && !aligned16(x1)) || (x_out != nullptr && !aligned16(x_out)) ||
+        (dmask != nullptr && (reinterpret_cast<uintptr_t>(dmask) & 3u) != 0))
         return BP_ERR_SHAPE;
     if (!(isfinite(epsilon) && epsilon >= 0.f)) return BP_ERR_SCALE;
-    // one residual dtype: when both x1 and x_out exist they must agree (reference ln_api.cpp:99-102)
+    // one residual dtype: when both x1 and x_out exist they must agree (reference ln_api.cpp:99-102);
+    // an fp32 x0 implies an fp32 residual stream
     if (x1 != nullptr && x_out != nullptr && (x1_is_f32 != 0) != (xout_is_f32 != 0)) return BP_ERR_DTYPE;
+    if (x0_is_f32 && ((x1 != nullptr && !x1_is_f32) || (x_out != nullptr && !xout_is_f32))) return BP_ERR_DTYPE;
     bp::LnParams p{};
     p.x0 = x0; p.x1 = x1; p.gamma = gamma; p.beta = beta; p.z = z; p.x_out = x_out;
     p.rows = rows; p.cols = cols; p.eps = epsilon;
     p.x1_f32 = x1_is_f32 ? 1 : 0; p.xo_f32 = xout_is_f32 ? 1 : 0; p.w_f32 = w_is_f32 ? 1 : 0;
+    p.x0_f32 = x0_is_f32 ? 1 : 0;
+    p.dmask = dmask; p.rng_state = rng_state;
+    if (!dropout_args(p_dropout, rng_state, p.drop_thr, p.drop_scale)) return BP_ERR_DROPOUT;
     hipError_t e = bp::launch_add_layer_norm(p, dtype, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
 }
@@ -348,19 +436,30 @@ int bp_add_layer_norm_bwd(const void *dz, const void *dx_in, const void *x, cons
                           void *dx0, void *dx1, void *dgamma, void *dbeta, float *ws,
                           int64_t rows, int cols, float epsilon, int dtype, int res_is_f32, int w_is_f32,
                           bp_stream_t stream) {
+    return bp_dropout_add_layer_norm_bwd(dz, dx_in, x, gamma, dx0, dx1, dgamma, dbeta, ws, rows, cols, epsilon, dtype,
+                                         0, res_is_f32, w_is_f32, 0.f, nullptr, stream);
+}
+
+int bp_dropout_add_layer_norm_bwd(const void *dz, const void *dx_in, const void *x, const void *gamma,
+                                  void *dx0, void *dx1, void *dgamma, void *dbeta, float *ws,
+                                  int64_t rows, int cols, float epsilon, int dtype, int x0_is_f32, int res_is_f32,
+                                  int w_is_f32, float p_dropout, const uint64_t *rng_state, bp_stream_t stream) {
     static_assert(BP_LN_BWD_WS_ROWS == bp::kLnBwdMaxWg, "workspace rows");
     if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
-    if (rows <= 0 || cols <= 0 || cols % 4 != 0 || cols > 2048) return BP_ERR_SHAPE;
+    if (rows <= 0 || rows > 0xffffffffLL || cols <= 0 || cols % 4 != 0 || cols > 2048) return BP_ERR_SHAPE;
     if (!dz || !x || !gamma || !dx0 || !dgamma || !dbeta || !ws) return BP_ERR_SHAPE;
     const void *ptrs[] = {dz, dx_in, x, gamma, dx0, dx1, dgamma, dbeta, ws};
     for (const void *ptr : ptrs) if (ptr != nullptr && !aligned16(ptr)) return BP_ERR_SHAPE;
     if (!(isfinite(epsilon) && epsilon >= 0.f)) return BP_ERR_SCALE;
+    if (x0_is_f32 && !res_is_f32) return BP_ERR_DTYPE;
     bp::LnBwdParams p{};
     p.dz = dz; p.dx_in = dx_in; p.x = x; p.gamma = gamma; p.dx0 = dx0; p.dx1 = dx1;
     p.dgamma = dgamma; p.dbeta = dbeta; p.ws = ws;
     p.rows = rows; p.cols = cols; p.eps = epsilon;
     p.n_wg = (int)((rows + 3) / 4 < bp::kLnBwdMaxWg ? (rows + 3) / 4 : bp::kLnBwdMaxWg);
-    p.res_f32 = res_is_f32 ? 1 : 0; p.w_f32 = w_is_f32 ? 1 : 0;
+    p.res_f32 = res_is_f32 ? 1 : 0; p.w_f32 = w_is_f32 ? 1 : 0; p.x0_f32 = x0_is_f32 ? 1 : 0;
+    p.rng_state = rng_state;
+    if (!dropout_args(p_dropout, rng_state, p.drop_thr, p.drop_scale)) return BP_ERR_DROPOUT;
     hipError_t e = bp::launch_add_layer_norm_bwd(p, dtype, static_cast<hipStream_t>(stream));
     if (e == hipErrorNotSupported) return BP_ERR_SHAPE;
     return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;

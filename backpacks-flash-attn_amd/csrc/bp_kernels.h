@@ -21,6 +21,10 @@ struct FlashParams {
     int causal;
     int pair;                 // flash_fwd_dma: one workgroup takes query tiles t and n-1-t (causal load balance)
     float scale_log2e;        // softmax_scale * log2(e)
+    // dropout (training): see bp_philox.h.  drop_thr == 0: no dropout.
+    const uint64_t *rng_state;   // device {seed, offset}
+    uint32_t drop_thr;           // keep iff u16 < drop_thr  (round((1-p) * 65536))
+    float drop_scale;            // 1 / (1 - p)
 };
 
 struct FlashBwdParams {
@@ -34,6 +38,9 @@ struct FlashBwdParams {
     int64_t lse_stride;
     int b, h, d, max_sq, max_sk, causal;
     float scale;
+    const uint64_t *rng_state;   // dropout, as in FlashParams (must be the forward's state)
+    uint32_t drop_thr;
+    float drop_scale;
 };
 
 hipError_t launch_flash_bwd(const FlashBwdParams &p, int dtype, hipStream_t stream);
@@ -50,6 +57,8 @@ struct ProbsParams {
     int p_vec;                // 1: 8-byte stores into P are aligned
     int p_vec16;              // 1: 16-byte stores at multiples of 8 keys are aligned (full-line path)
     float scale_log2e;
+    const uint64_t *rng_state;   // dropout: dropped entries are stored NEGATED (sign bit), see bp_attn_probs_dropout
+    uint32_t drop_thr;
 };
 
 struct MixParams {
@@ -94,7 +103,7 @@ hipError_t launch_xentropy_fwd(const XentParams &p, int dtype, hipStream_t strea
 hipError_t launch_xentropy_bwd(const XentParams &p, int dtype, hipStream_t stream);
 
 struct LnParams {
-    const void *x0;           // (rows, cols) 16-bit
+    const void *x0;           // (rows, cols) 16-bit, or fp32 when x0_f32 (then z is fp32 too)
     const void *x1;           // (rows, cols) residual in, 16-bit or fp32, may be NULL
     const void *gamma, *beta; // (cols) 16-bit or fp32
     void *z;                  // (rows, cols) in x0's dtype
@@ -103,6 +112,11 @@ struct LnParams {
     int cols;
     int x1_f32, xo_f32, w_f32;
     float eps;
+    int x0_f32;
+    uint8_t *dmask;              // optional (rows, cols) keep mask out (1 = kept), only written with dropout
+    const uint64_t *rng_state;   // dropout on x0 (bp_philox.h); drop_thr == 0: none
+    uint32_t drop_thr;
+    float drop_scale;
 };
 
 hipError_t launch_add_layer_norm(const LnParams &p, int dtype, hipStream_t stream);
@@ -121,6 +135,10 @@ struct LnBwdParams {
     int cols, n_wg;
     int res_f32, w_f32;
     float eps;
+    int x0_f32;                  // dz and dx0 are fp32 (the forward's x0 / z dtype)
+    const uint64_t *rng_state;   // the forward's dropout state: dx0 = dropout-masked, rescaled dx
+    uint32_t drop_thr;
+    float drop_scale;
 };
 hipError_t launch_add_layer_norm_bwd(const LnBwdParams &p, int dtype, hipStream_t stream);
 hipError_t launch_flash_fwd(const FlashParams &p, int dtype, bool vec, hipStream_t stream);

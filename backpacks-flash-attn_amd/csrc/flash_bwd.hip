@@ -8,6 +8,9 @@
 //     P_ij  = exp(scale * q_i.k_j - L_i)            dV_j = sum_i P_ij dO_i
 //     dP_ij = dO_i . v_j                            dS_ij = P_ij (dP_ij - D_i)
 //     dQ_i  = scale * sum_j dS_ij k_j               dK_j = scale * sum_i dS_ij q_i
+// With attention dropout (training; reference fmha_dgrad_kernel_1xN_loop.h:405-711 regenerates its Philox mask the
+// same way): Z_ij = keep_ij / (1 - p) from bp_philox.h, the forward's mask bit for bit, and
+//     dV_j = sum_i Z_ij P_ij dO_i                   dP_ij = Z_ij (dO_i . v_j)        (D_i already carries Z through O)
 //
 // Two kernels, both deterministic (no atomics -- the reference's sequence-parallel variant adds dQ
 // with atomics and is only allclose-reproducible, tests/test_flash_attn.py:768-772):
@@ -24,6 +27,7 @@
 #include "bp_common.h"
 #include "bp_dma.h"
 #include "bp_kernels.h"
+#include "bp_philox.h"
 
 namespace bp {
 
@@ -76,7 +80,7 @@ struct DkdvCfg {
 };
 
 // one 128-key tile `kt` of (sample, head) `bh`
-template <class ET, int KD, int NV>
+template <class ET, int KD, int NV, bool DROP>
 BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32_t lds0, const int bh, const int kt) {
     using C = BwdCfg<KD, NV>;
     using E = Elem<ET>;
@@ -126,6 +130,9 @@ BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32
         for (int off = tid * 16; off < C::NSTAGE * STAGE; off += C::NT * 16) lds_write_16B(smem, off, z);
         __syncthreads();
     }
+
+    DropoutStream rng = {0u, 0u};
+    if (DROP) rng = dropout_stream(p.rng_state, (uint32_t)bh);
 
     // ---- K and V fragments of my 32 keys: B operands (lane = key, 8 consecutive d) -----------------
     u32x4 kf[KD], vf[KD];
@@ -226,6 +233,8 @@ BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32
             }
             // ---- P = exp2(S*c - L*log2e), dS = P (dP - D) ------------------------------------------------
             u32x4 pf[2], dsf[2];
+            uint32_t keep = 0xffffu;   // bit 4g+i: query qbase + 8g + 4hh + i keeps my key
+            if (DROP) keep = dropout_keep_collane(rng, p.drop_thr, (uint32_t)qbase, (uint32_t)my_key, hh);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const u32x4 l4 = lds_read_16B(stats, (qb * 32 + 8 * g + 4 * hh) * 4);
@@ -238,8 +247,10 @@ BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32
                     float pv = fast_exp2(fmaf(s_[r], c2, -as_f32(l4[i]) * kLog2e));
                     const bool dead = q >= seq_q || my_key >= seq_k || (p.causal && my_key > q);
                     // selects, not multiplies: L / D of rows past the sequence are uninitialised (maybe NaN)
-                    pe[i] = dead ? 0.f : pv;
-                    de[i] = dead ? 0.f : pv * (dp[r] - as_f32(d4[i]));
+                    float z = 1.f;
+                    if (DROP) z = ((keep >> r) & 1u) ? p.drop_scale : 0.f;
+                    pe[i] = dead ? 0.f : (DROP ? pv * z : pv);
+                    de[i] = dead ? 0.f : pv * ((DROP ? dp[r] * z : dp[r]) - as_f32(d4[i]));
                 }
                 // regs 8*ks .. 8*ks+7 are the B operand of K-step ks (queries {0..3, 8..11} + 4hh + 16ks)
                 pf[g >> 1][(g & 1) * 2 + 0] = E::pack2(pe[0], pe[1]);
@@ -291,7 +302,7 @@ BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32
 // dQ
 // =====================================================================================================
 // one 128-query tile `qt` of (sample, head) `bh`
-template <class ET, int KD, int NV>
+template <class ET, int KD, int NV, bool DROP>
 BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t lds0, const int bh, const int qt) {
     using C = BwdCfg<KD, NV>;
     using E = Elem<ET>;
@@ -338,6 +349,9 @@ BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t
         for (int off = tid * 16; off < C::NSTAGE * STAGE; off += C::NT * 16) lds_write_16B(smem, off, z);
         __syncthreads();
     }
+
+    DropoutStream rng = {0u, 0u};
+    if (DROP) rng = dropout_stream(p.rng_state, (uint32_t)bh);
 
     u32x4 qf[KD], dof[KD];
     float lse2 = 0.f, dsum = 0.f;
@@ -438,6 +452,8 @@ BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t
                 dpt = E::mfma(b, dof[s], dpt);
             }
             u32x4 dsf[2];
+            uint32_t keep = 0xffffu;   // bit 4g+i: my query keeps key kbase + 8g + 4hh + i
+            if (DROP) keep = dropout_keep_rowlane(rng, p.drop_thr, (uint32_t)my_q, (uint32_t)kbase, hh);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float de[4];
@@ -447,7 +463,9 @@ BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t
                     const int key = kbase + 8 * g + 4 * hh + i;
                     const float pv = fast_exp2(fmaf(st_[r], c2, -lse2));
                     const bool dead = key >= seq_k || (p.causal && key > my_q);
-                    de[i] = dead ? 0.f : pv * (dpt[r] - dsum);
+                    float dpe = dpt[r];
+                    if (DROP) dpe = ((keep >> r) & 1u) ? dpe * p.drop_scale : 0.f;
+                    de[i] = dead ? 0.f : pv * (dpe - dsum);
                 }
                 dsf[g >> 1][(g & 1) * 2 + 0] = E::pack2(de[0], de[1]);
                 dsf[g >> 1][(g & 1) * 2 + 1] = E::pack2(de[2], de[3]);
@@ -488,7 +506,7 @@ BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t
 
 // Kernels: a causal workgroup takes the heaviest remaining tile and the lightest of its (sample, head) -- tiles t
 // and n-1-t -- so that every workgroup carries the same work (in-order round-robin dispatch, see flash_fwd_dma.hip).
-template <class ET, int KD, int NV>
+template <class ET, int KD, int NV, bool DROP>
 __global__ __launch_bounds__(256) void flash_bwd_dkdv_kernel(const FlashBwdParams p) {
     __shared__ __attribute__((aligned(16))) char smem[DkdvCfg<KD, NV>::SMEM];
     const uint32_t lds0 = lds_base_addr(smem);
@@ -500,11 +518,11 @@ __global__ __launch_bounds__(256) void flash_bwd_dkdv_kernel(const FlashBwdParam
     const int npass = (pair && other != slot) ? 2 : 1;
     for (int pass = 0; pass < npass; ++pass) {
         if (pass) __syncthreads();
-        flash_bwd_dkdv_tile<ET, KD, NV>(p, smem, lds0, bh, pass ? other : slot);
+        flash_bwd_dkdv_tile<ET, KD, NV, DROP>(p, smem, lds0, bh, pass ? other : slot);
     }
 }
 
-template <class ET, int KD, int NV>
+template <class ET, int KD, int NV, bool DROP>
 __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashBwdParams p) {
     using C = BwdCfg<KD, NV>;
     __shared__ __attribute__((aligned(16))) char smem[C::NSTAGE * (2 * C::RTILE + C::TTILE)];
@@ -517,21 +535,26 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashBwdParams 
     const int npass = (pair && heavy != slot) ? 2 : 1;
     for (int pass = 0; pass < npass; ++pass) {
         if (pass) __syncthreads();
-        flash_bwd_dq_tile<ET, KD, NV>(p, smem, lds0, bh, pass ? slot : heavy);
+        flash_bwd_dq_tile<ET, KD, NV, DROP>(p, smem, lds0, bh, pass ? slot : heavy);
     }
+}
+
+template <class ET, int KD, int NV, bool DROP>
+static hipError_t launch_drop(const FlashBwdParams &p, hipStream_t stream) {
+    // dq first: it also produces the D vector the dkdv kernel consumes
+    const int nq = (p.max_sq + 127) / 128, nk = (p.max_sk + 127) / 128;
+    const int gq = xcd_grid(p.b * p.h, (p.causal && nq > 1) ? (nq + 1) / 2 : nq);
+    hipLaunchKernelGGL((flash_bwd_dq_kernel<ET, KD, NV, DROP>), dim3(gq), dim3(256), 0, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int gk = xcd_grid(p.b * p.h, (p.causal && nk > 1) ? (nk + 1) / 2 : nk);
+    hipLaunchKernelGGL((flash_bwd_dkdv_kernel<ET, KD, NV, DROP>), dim3(gk), dim3(256), 0, stream, p);
+    return hipGetLastError();
 }
 
 template <class ET, int KD, int NV>
 static hipError_t launch_one(const FlashBwdParams &p, hipStream_t stream) {
-    // dq first: it also produces the D vector the dkdv kernel consumes
-    const int nq = (p.max_sq + 127) / 128, nk = (p.max_sk + 127) / 128;
-    const int gq = xcd_grid(p.b * p.h, (p.causal && nq > 1) ? (nq + 1) / 2 : nq);
-    hipLaunchKernelGGL((flash_bwd_dq_kernel<ET, KD, NV>), dim3(gq), dim3(256), 0, stream, p);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    const int gk = xcd_grid(p.b * p.h, (p.causal && nk > 1) ? (nk + 1) / 2 : nk);
-    hipLaunchKernelGGL((flash_bwd_dkdv_kernel<ET, KD, NV>), dim3(gk), dim3(256), 0, stream, p);
-    return hipGetLastError();
+    return p.drop_thr != 0u ? launch_drop<ET, KD, NV, true>(p, stream) : launch_drop<ET, KD, NV, false>(p, stream);
 }
 
 template <class ET>

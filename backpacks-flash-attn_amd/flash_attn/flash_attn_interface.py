@@ -4,8 +4,10 @@ flash_attn/flash_attn_interface.py (public functions :242-380), with `flash_attn
 `flash_attn_cuda.bwd` (:38-43) by bp_hip.flash_bwd (bp_flash_bwd).
 
 The HIP backward covers the same head dims as the forward fast path (% 8 == 0, <= 128); for anything
-else the autograd Functions fall back to differentiating an eager recomputation.  Dropout inside the
-kernel is not implemented; `dropout_p` must be 0 as it is in eval / the forward benchmark.
+else the autograd Functions fall back to differentiating an eager recomputation (dropout_p = 0 only).
+Attention dropout runs inside the kernels (bp_flash_fwd_dropout / bp_flash_bwd_dropout): the forward draws a
+two-word generator state on the device from torch's CUDA generator and saves it for backward, where the
+reference saves and restores the whole CUDA RNG state around its kernel (:56-57,:74-81).
 """
 import torch
 
@@ -20,33 +22,36 @@ def _get_block_size(device, head_dim, is_dropout):
 
 def _flash_attn_forward(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k,
                         dropout_p, softmax_scale, causal, return_softmax, num_splits=0,
-                        generator=None):
+                        generator=None, rng_state=None):
     """Same contract as the reference's helper (:13-28): writes `out` in place and returns
     (out, softmax_lse, S_dmask).  `S_dmask` here is the NORMALISED probability tensor
-    (b, h, max_seqlen_q, max_seqlen_k), only for fixed-length batches (testing aid, as upstream)."""
-    if dropout_p != 0.0:
-        raise RuntimeError('flash_attn (gfx950 build): in-kernel dropout is not implemented; '
-                           'call with dropout_p=0.0 (eval mode)')
+    (b, h, max_seqlen_q, max_seqlen_k), only for fixed-length batches (testing aid, as upstream); with
+    dropout, dropped entries carry a set sign bit (the reference encodes its mask in the sign of S_dmask too,
+    tests/test_flash_attn.py:181-236).  `rng_state`: bp_hip.new_rng_state(); required when dropout_p > 0 and
+    the mask must be reproducible (backward)."""
+    if generator is not None:
+        raise RuntimeError('flash_attn (gfx950 build): pass rng_state (bp_hip.new_rng_state) instead of a generator')
+    if dropout_p > 0.0 and rng_state is None:
+        rng_state = bp_hip.new_rng_state(q.device)
     softmax_lse = bp_hip.flash_fwd(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q,
-                                   max_seqlen_k, softmax_scale, causal)
+                                   max_seqlen_k, softmax_scale, causal, dropout_p, rng_state)
     S_dmask = None
     if return_softmax:
         batch = cu_seqlens_q.numel() - 1 if cu_seqlens_q is not None else q.shape[0] // max_seqlen_q
         if q.shape[0] == batch * max_seqlen_q and k.shape[0] == batch * max_seqlen_k:
             qb = q.unflatten(0, (batch, max_seqlen_q))
             kb = k.unflatten(0, (batch, max_seqlen_k))
-            S_dmask = bp_hip.attn_probs(qb, kb, softmax_lse, softmax_scale, causal)
+            S_dmask = bp_hip.attn_probs(qb, kb, softmax_lse, softmax_scale, causal, dropout_p, rng_state)
     return out, softmax_lse, S_dmask
 
 
 def _flash_attn_backward(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seqlens_k,
                          max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale, causal, num_splits=0,
-                         generator=None):
-    """Same contract as the reference's helper (:31-47): fills dq, dk, dv in place."""
-    if dropout_p != 0.0:
-        raise RuntimeError('flash_attn (gfx950 build): in-kernel dropout is not implemented')
+                         generator=None, rng_state=None):
+    """Same contract as the reference's helper (:31-47): fills dq, dk, dv in place.  With dropout, `rng_state`
+    is the forward's (the reference restores the saved CUDA RNG state instead, :74-81)."""
     bp_hip.flash_bwd(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seqlens_k,
-                     max_seqlen_q, max_seqlen_k, softmax_scale, causal)
+                     max_seqlen_q, max_seqlen_k, softmax_scale, causal, dropout_p, rng_state)
     return dq, dk, dv
 
 
@@ -76,8 +81,10 @@ class _FlashAttnFuncBase(torch.autograd.Function):
     def _fwd(ctx, q, k, v, cu_q, cu_k, max_q, max_k, dropout_p, softmax_scale, causal, return_softmax):
         if softmax_scale is None:
             softmax_scale = q.shape[-1] ** (-0.5)
+        rng_state = bp_hip.new_rng_state(q.device) if dropout_p > 0.0 else None
         out, lse, S = _flash_attn_forward(q, k, v, torch.empty_like(q), cu_q, cu_k, max_q, max_k,
-                                          dropout_p, softmax_scale, causal, return_softmax)
+                                          dropout_p, softmax_scale, causal, return_softmax, rng_state=rng_state)
+        ctx.dropout_p, ctx.rng_state = dropout_p, rng_state
         ctx.softmax_scale, ctx.causal = softmax_scale, causal
         ctx.max_q, ctx.max_k = max_q, max_k
         return out, lse, S
@@ -90,7 +97,10 @@ class _FlashAttnFuncBase(torch.autograd.Function):
             dq, dk, dv = grads if grads is not None else (torch.empty_like(q), torch.empty_like(k),
                                                           torch.empty_like(v))
             return _flash_attn_backward(dout, q, k, v, out, lse, dq, dk, dv, cu_q, cu_k, ctx.max_q,
-                                        ctx.max_k, 0.0, ctx.softmax_scale, ctx.causal)
+                                        ctx.max_k, ctx.dropout_p, ctx.softmax_scale, ctx.causal,
+                                        rng_state=ctx.rng_state)
+        if ctx.dropout_p > 0.0:
+            raise RuntimeError('flash_attn (gfx950 build): attention dropout needs head_dim % 8 == 0 and <= 128')
         with torch.enable_grad():
             q_, k_, v_ = (t.detach().requires_grad_() for t in (q, k, v))
             out = _eager_varlen(q_, k_, v_, cu_q, cu_k, ctx.softmax_scale, ctx.causal, ctx.max_q, ctx.max_k)

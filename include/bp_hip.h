@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define BP_ABI_VERSION 1
+#define BP_ABI_VERSION 2   /* 2: *_dropout entry points added (nothing removed or changed) */
 
 /* element type of q/k/v/out/content tensors */
 #define BP_DTYPE_F16 0
@@ -35,6 +35,7 @@ extern "C" {
 #define BP_ERR_SCALE -4       /* softmax_scale is not finite or not > 0                                     */
 #define BP_ERR_LAUNCH -5      /* hipLaunchKernel failed (FMHA_CHECK_CUDA, src/fmha_utils.h:39)              */
 #define BP_ERR_DOUT -6        /* sense mix: d_out < 1                                                       */
+#define BP_ERR_DROPOUT -7     /* p_dropout outside [0,1), rng_state NULL with p > 0, or a shape the dropout path lacks */
 
 typedef void *bp_stream_t; /* a hipStream_t */
 
@@ -70,6 +71,30 @@ int bp_flash_fwd(const void *q, const void *k, const void *v, void *out, float *
                  bp_stream_t stream);
 
 /*
+ * bp_flash_fwd_dropout -- bp_flash_fwd with in-kernel attention dropout (training): replaces the p_dropout > 0
+ * path of flash_attn_cuda.fwd (csrc/flash_attn/fmha_api.cpp:199,306-320; kernel
+ * src/fmha_fprop_kernel_1xN.h:494-506).  O = (dropout(P) / (1 - p)) V; the row log-sum-exp is that of the
+ * UNdropped probabilities, as upstream.
+ *   p_dropout  in [0, 1); 0 = identical to bp_flash_fwd (rng_state may then be NULL)
+ *   rng_state  DEVICE pointer to two uint64 {seed, offset} (the role of the at::Generator's philox state,
+ *              fmha_api.cpp:314-320).  Read by the kernel, never written; hand the SAME two words to
+ *              bp_flash_bwd_dropout / bp_attn_probs_dropout to regenerate the same mask.  The mask is a pure
+ *              function of (seed, offset, batch*nheads index, query index, key index): Philox2x32-10 keyed per
+ *              (batch, head), one call per run of 4 keys, 16-bit uniforms against round((1-p) * 65536)
+ *              (csrc/bp_philox.h; tests/philox_ref.py restates it on the host).
+ * Dropout needs the 16-byte vector path (head_dim % 8 == 0, aligned rows); BP_ERR_DROPOUT otherwise.
+ */
+int bp_flash_fwd_dropout(const void *q, const void *k, const void *v, void *out, float *softmax_lse,
+                         const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k,
+                         int batch, int nheads, int head_dim, int max_seqlen_q, int max_seqlen_k,
+                         int64_t q_row_stride, int64_t q_head_stride,
+                         int64_t k_row_stride, int64_t k_head_stride,
+                         int64_t v_row_stride, int64_t v_head_stride,
+                         int64_t o_row_stride, int64_t o_head_stride,
+                         int64_t lse_stride, float softmax_scale, int is_causal, int dtype,
+                         float p_dropout, const uint64_t *rng_state, bp_stream_t stream);
+
+/*
  * bp_attn_probs -- materialise normalised attention probabilities
  *   P[b,h,i,j] = exp(scale * q_i.k_j - lse[b,h,i])  for visible (i,j), exactly 0 elsewhere.
  * Serves `return_attn_probs=True` of the flash interface (flash_attn_interface.py:242-267; the
@@ -84,6 +109,21 @@ int bp_attn_probs(const void *q, const void *k, const float *softmax_lse, void *
                   int64_t lse_stride,
                   int64_t p_batch_stride, int64_t p_head_stride, int64_t p_row_stride,
                   float softmax_scale, int is_causal, int dtype, bp_stream_t stream);
+
+/*
+ * bp_attn_probs_dropout -- bp_attn_probs that also reports the dropout mask of bp_flash_fwd_dropout called with
+ * the same (p_dropout, rng_state): a DROPPED entry is stored with its sign bit set (-P, or -0.0), a kept one
+ * as +P.  Same encoding idea as the reference's S_dmask (fmha_api.cpp:279; tests/test_flash_attn.py:181-236
+ * decode it with `S >= 0`); here P is already normalised, so decode with the sign BIT, not with `< 0`.
+ */
+int bp_attn_probs_dropout(const void *q, const void *k, const float *softmax_lse, void *probs,
+                          int batch, int nheads, int head_dim, int seqlen_q, int seqlen_k,
+                          int64_t q_batch_stride, int64_t q_row_stride, int64_t q_head_stride,
+                          int64_t k_batch_stride, int64_t k_row_stride, int64_t k_head_stride,
+                          int64_t lse_stride,
+                          int64_t p_batch_stride, int64_t p_head_stride, int64_t p_row_stride,
+                          float softmax_scale, int is_causal, int dtype,
+                          float p_dropout, const uint64_t *rng_state, bp_stream_t stream);
 
 /*
  * bp_sense_lse -- log-sum-exp of every (sense, query) row of the causal sense attention:
@@ -186,6 +226,27 @@ int bp_flash_bwd(const void *dout, const void *q, const void *k, const void *v, 
                  bp_stream_t stream);
 
 /*
+ * bp_flash_bwd_dropout -- bp_flash_bwd for a forward that ran bp_flash_fwd_dropout: the p_dropout > 0 path of
+ * flash_attn_cuda.bwd (fmha_api.cpp:337-504), which upstream feeds with the generator state saved by the
+ * forward (flash_attn_interface.py:53-68: `rng_state`).  `out` must be the dropped-out forward output and
+ * (p_dropout, rng_state) the forward's; the kernels regenerate the mask.
+ */
+int bp_flash_bwd_dropout(const void *dout, const void *q, const void *k, const void *v, const void *out,
+                         const float *softmax_lse, float *dsum_ws, void *dq, void *dk, void *dv,
+                         const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k,
+                         int batch, int nheads, int head_dim, int max_seqlen_q, int max_seqlen_k,
+                         int64_t do_row_stride, int64_t do_head_stride,
+                         int64_t q_row_stride, int64_t q_head_stride,
+                         int64_t k_row_stride, int64_t k_head_stride,
+                         int64_t v_row_stride, int64_t v_head_stride,
+                         int64_t o_row_stride, int64_t o_head_stride,
+                         int64_t dq_row_stride, int64_t dq_head_stride,
+                         int64_t dk_row_stride, int64_t dk_head_stride,
+                         int64_t dv_row_stride, int64_t dv_head_stride,
+                         int64_t lse_stride, float softmax_scale, int is_causal, int dtype,
+                         float p_dropout, const uint64_t *rng_state, bp_stream_t stream);
+
+/*
  * bp_add_layer_norm -- fused residual add + LayerNorm forward (eval path):
  *   x = x0 + x1 ;  z = (x - mean) * rsqrt(var + eps) * gamma + beta     (fp32 math)
  * Replaces dropout_layer_norm.dropout_add_ln_fwd with dropout_p = 0 and no rowscale / colscale /
@@ -203,6 +264,23 @@ int bp_flash_bwd(const void *dout, const void *q, const void *k, const void *v, 
 int bp_add_layer_norm(const void *x0, const void *x1, const void *gamma, const void *beta, void *z,
                       void *x_out, int64_t rows, int cols, float epsilon, int dtype, int x1_is_f32,
                       int xout_is_f32, int w_is_f32, bp_stream_t stream);
+
+/*
+ * bp_dropout_add_layer_norm -- the full forward of the reference's dropout_add_ln_fwd minus rowscale / colscale /
+ * subset (csrc/layer_norm/ln_api.cpp:83-254; kernel ln_fwd_kernels.cuh:76,112-134):
+ *   x = dropout(x0) / (1 - p) + x1 ;  z = LayerNorm(x)
+ * Arguments as bp_add_layer_norm, plus
+ *   x0_is_f32  x0 (and therefore z: otype = itype, ln_api.cpp:104) is fp32 instead of `dtype` -- the AMP case,
+ *              where the fp32 embedding output enters the first LayerNorm; requires an fp32 residual stream
+ *   dmask      optional (rows, cols) uint8 keep mask out (1 = kept; 4-byte aligned), written only when p_dropout > 0
+ *              -- what `return_dropout_mask=True` hands back (flash_attn/ops/layer_norm.py:207-217)
+ *   p_dropout, rng_state   as in bp_flash_fwd_dropout; here ONE stream per call with counter (row, column / 4)
+ * rows must be < 2^32.
+ */
+int bp_dropout_add_layer_norm(const void *x0, const void *x1, const void *gamma, const void *beta, void *z,
+                              void *x_out, uint8_t *dmask, int64_t rows, int cols, float epsilon, int dtype,
+                              int x0_is_f32, int x1_is_f32, int xout_is_f32, int w_is_f32,
+                              float p_dropout, const uint64_t *rng_state, bp_stream_t stream);
 
 /*
  * bp_softmax_bwd_causal -- backward of the causal softmax behind the sense weights (training path of
@@ -231,6 +309,17 @@ int bp_add_layer_norm_bwd(const void *dz, const void *dx_in, const void *x, cons
                           void *dx0, void *dx1, void *dgamma, void *dbeta, float *ws,
                           int64_t rows, int cols, float epsilon, int dtype, int res_is_f32, int w_is_f32,
                           bp_stream_t stream);
+
+/*
+ * bp_dropout_add_layer_norm_bwd -- backward of bp_dropout_add_layer_norm (dropout_add_ln_bwd,
+ * ln_api.cpp:256-408): as bp_add_layer_norm_bwd, with dx0 = dropout-masked dx / (1 - p) (dx1 stays dx).  The
+ * mask is regenerated from the forward's (p_dropout, rng_state); the reference reads its saved dmask instead.
+ *   x0_is_f32  dz and dx0 are fp32 (the forward's x0 / z dtype)
+ */
+int bp_dropout_add_layer_norm_bwd(const void *dz, const void *dx_in, const void *x, const void *gamma,
+                                  void *dx0, void *dx1, void *dgamma, void *dbeta, float *ws,
+                                  int64_t rows, int cols, float epsilon, int dtype, int x0_is_f32, int res_is_f32,
+                                  int w_is_f32, float p_dropout, const uint64_t *rng_state, bp_stream_t stream);
 
 /*
  * bp_xentropy_fwd / bp_xentropy_bwd -- fused softmax cross-entropy over vocabulary-sized rows.

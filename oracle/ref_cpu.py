@@ -60,13 +60,16 @@ def self_attention_eager(qkv, causal=False, softmax_scale=None, key_padding_mask
 
 def attention_fp32(q, k, v=None, causal=False, softmax_scale=None,
                    query_padding_mask=None, key_padding_mask=None,
-                   upcast=True, reorder_ops=False):
+                   upcast=True, reorder_ops=False, dropout_p=0.0, dropout_mask=None):
     """The reference's own test oracle: tests/test_flash_attn.py:129-178, extended with an
     explicit softmax_scale (the reference hard-codes 1/sqrt(d)) and with the row
     log-sum-exp the kernel returns (fmha_fprop_kernel_1xN.h:592-596).
 
     q (B,Sq,H,D), k/v (B,Sk,H,D).  Masks are -inf; causal is top-left aligned
     (col <= row, csrc/flash_attn/src/fmha/mask.h:57-70).
+    dropout_mask (B,H,Sq,Sk) bool, True = keep, with dropout_p: the reference oracle's dropout arguments
+    (tests/test_flash_attn.py:131,166-171): out = (attn masked by dropout_mask) @ (v / (1 - dropout_p)); the
+    returned `attn` stays the UNdropped softmax, as upstream (:172-178).
     Returns (out (B,Sq,H,D) in q's dtype or None, attn (B,H,Sq,Sk), lse (B,H,Sq) fp32).
     """
     dtype_og = q.dtype
@@ -89,8 +92,13 @@ def attention_fp32(q, k, v=None, causal=False, softmax_scale=None,
     # rows with no valid key: softmax gives NaN, the kernel gives zeros / lse=-inf
     attn = torch.nan_to_num(attn, nan=0.0)
     out = None
+    if dropout_mask is not None:
+        attn_used = attn.masked_fill(~dropout_mask, 0.0)
+    else:
+        attn_used = attn
+    dropout_scaling = 1.0 / (1.0 - dropout_p)
     if v is not None:
-        out = torch.einsum('bhts,bshd->bthd', attn, v)
+        out = torch.einsum('bhts,bshd->bthd', attn_used, v * dropout_scaling)
         if query_padding_mask is not None:
             out = out.masked_fill(~query_padding_mask[:, :, None, None], 0.0)
         out = out.to(dtype_og)

@@ -61,6 +61,12 @@ def test_argument_validation_returns_before_any_launch():
     for bad in (float('nan'), float('inf'), 0.0, -1.0):
         assert h.bp_flash_fwd(p, p, p, p, p, null, null, 1, 1, 64, 16, 16, 64, 64, 64, 64, 64, 64, 64,
                               64, 16, bad, 1, 1, null) == -4
+    # dropout: p outside [0, 1), p > 0 without a generator state, dropout on an LSE-only call
+    tail = (1, 1, 64, 16, 16, 64, 64, 64, 64, 64, 64, 64, 64, 16, 0.125, 1, 1)
+    assert h.bp_flash_fwd_dropout(p, p, p, p, p, null, null, *tail, 1.0, p, null) == -7
+    assert h.bp_flash_fwd_dropout(p, p, p, p, p, null, null, *tail, -0.1, p, null) == -7
+    assert h.bp_flash_fwd_dropout(p, p, p, p, p, null, null, *tail, 0.1, null, null) == -7
+    assert h.bp_flash_fwd_dropout(p, p, null, null, p, null, null, *tail, 0.1, p, null) == -7
     # sense mix: d_out < 1, d_k out of range
     assert h.bp_sense_mix(p, p, p, p, 0, 1, 16, 4, 16, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0.25, 1, null) == -6
     assert h.bp_sense_mix(p, p, p, p, 0, 1, 16, 4, 200, 64, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0.25, 1, null) == -2
@@ -80,6 +86,25 @@ def test_argument_validation_returns_before_any_launch():
                           null) == -3
     assert h.bp_flash_bwd(p, p, p, p, p, p, p, p, p, p, null, null, 1, 1, 64, 16, 16, *st, 16, -1.0, 1, 1,
                           null) == -4
+    assert h.bp_flash_bwd_dropout(p, p, p, p, p, p, p, p, p, p, null, null, 1, 1, 64, 16, 16, *st, 16, 0.125, 1, 1,
+                                  0.5, null, null) == -7
+    assert h.bp_attn_probs_dropout(p, p, p, p, 1, 1, 64, 16, 16, 1, 1, 1, 1, 1, 1, 16, 1, 1, 1, 0.125, 1, 1,
+                                   2.0, p, null) == -7
+
+
+def test_philox_restatement_known_answers():
+    """tests/philox_ref.py (the host restatement of csrc/bp_philox.h) against the published Philox2x32-10
+    known-answer vectors of Random123 (kat_vectors: three `philox2x32 10` lines)."""
+    import philox_ref as P
+    for (c0, c1, key), want in (((0, 0, 0), (0xff1dae59, 0x6cd10df2)),
+                                ((0xffffffff, 0xffffffff, 0xffffffff), (0x2c3f628b, 0xab4fd7ad)),
+                                ((0x243f6a88, 0x85a308d3, 0x13198a2e), (0xdd7ce038, 0xf62a4c12))):
+        a, b = P.philox2x32(c0, c1, key)
+        assert (int(a), int(b)) == want
+    keep = P.attention_keep_mask(123, 456, 2, 3, 96, 160, 0.17)
+    assert keep.shape == (2, 3, 96, 160) and abs(keep.mean() - 0.83) < 0.01
+    assert not (keep[0, 0] == keep[0, 1]).all() and not (keep[0, 0] == keep[1, 0]).all()   # streams differ per (b, h)
+    assert P.threshold(0.1) == 58982 and P.threshold(0.17) == 54395
 
 
 def test_python_binding_refuses_cpu_tensors_loudly():

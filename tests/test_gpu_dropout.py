@@ -1,0 +1,246 @@
+"""-m gpu: in-kernel dropout (training path) -- attention (bp_flash_fwd_dropout / bp_flash_bwd_dropout /
+bp_attn_probs_dropout) and the fused dropout + add + LayerNorm (bp_dropout_add_layer_norm[_bwd]).
+
+The reference checks dropout statistically and through the mask its kernel reports (S_dmask,
+tests/test_flash_attn.py:376-437).  Here the mask is ALSO a documented pure function of the generator state
+(csrc/bp_philox.h), restated on the host in tests/philox_ref.py, so the first thing tested is bit-exact agreement
+of kernel and restatement; the numerics then run against the fp32 oracle WITH that mask (the reference's own
+procedure: attention_ref(..., dropout_p, dropout_mask), :397-400), and the reference's bounds apply:
+output <= 2x, gradients <= 4x the eager same-dtype error, dropout fraction within 2 % of p (:424-437)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import philox_ref as P
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _bp():
+    import bp_hip
+    return bp_hip
+
+
+def _state(seed, offset):
+    return torch.tensor([seed, offset], dtype=torch.int64, device=DEV)
+
+
+@pytest.mark.parametrize('causal', [False, True])
+@pytest.mark.parametrize('shape', [(2, 3, 200, 64), (1, 2, 128, 128), (2, 2, 77, 40), (1, 4, 1024, 64)])
+def test_attention_dropout_mask_is_the_documented_function(shape, causal):
+    """S_dmask sign bits == tests/philox_ref.py, bit for bit; magnitudes == the undropped probabilities."""
+    bp = _bp()
+    b, h, s, d = shape
+    p_drop, seed, offset = 0.17, 0x1234567890ABCDEF - 2 ** 64, 987654321
+    torch.manual_seed(0)
+    qkv = torch.randn(b, s, 3, h, d, device=DEV, dtype=torch.bfloat16)
+    q, k, v = qkv.unbind(2)
+    out = torch.empty_like(q)
+    rng = _state(seed, offset)
+    lse = bp.flash_fwd(q.flatten(0, 1), k.flatten(0, 1), v.flatten(0, 1), out.flatten(0, 1), None, None, s, s,
+                       d ** -0.5, causal, p_drop, rng)
+    probs = bp.attn_probs(q, k, lse, d ** -0.5, causal, p_drop, rng)
+    plain = bp.attn_probs(q, k, lse, d ** -0.5, causal)
+    want = torch.from_numpy(P.attention_keep_mask(seed, offset, b, h, s, s, p_drop))
+    got = ~torch.signbit(probs.float()).cpu()
+    visible = torch.ones(s, s, dtype=torch.bool).tril() if causal else torch.ones(s, s, dtype=torch.bool)
+    assert torch.equal(got[..., visible], want[..., visible])
+    assert torch.equal(probs.abs(), plain)
+    frac = 1.0 - want[..., visible].float().mean().item()
+    assert 0.98 <= frac / p_drop <= 1.02 or s < 128, frac      # the reference's statistic (:433)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('causal', [False, True])
+@pytest.mark.parametrize('d', [128, 64, 80, 40, 32, 16])
+@pytest.mark.parametrize('seqlen', [97, 128, 200, 256, 512])
+def test_flash_dropout_qkvpacked(seqlen, d, causal, dtype):
+    """The p = 0.17 half of the reference's test_flash_attn_unpadded_qkvpacked (tests/test_flash_attn.py:350-437):
+    random key-padding masks through unpad -> flash_attn_unpadded_qkvpacked_func(dropout_p=0.17) -> pad, forward
+    and backward against the oracle given the kernel's own mask."""
+    from flash_attn.bert_padding import pad_input, unpad_input
+    from flash_attn.flash_attn_interface import FlashAttnQKVPackedFunc
+    bp = _bp()
+    p_drop = 0.17
+    gen = torch.Generator().manual_seed(seqlen * 7 + d)
+    batch, h = 3, 2
+    x = torch.randn(batch, seqlen, 3, h, d, generator=gen).to(dtype)
+    lengths = torch.randint(max(1, seqlen - 20), seqlen + 1, (batch,), generator=gen)
+    if (seqlen + d) % 3 == 0:
+        lengths[:] = seqlen
+    mask = torch.arange(seqlen)[None, :] < lengths[:, None]
+    qkv = x.to(DEV).requires_grad_()
+    rows, indices, cu, max_len = unpad_input(qkv.flatten(2), mask.to(DEV))
+    torch.manual_seed(seqlen + d)          # the Function draws its generator state from torch's CUDA generator
+    out_unpad = FlashAttnQKVPackedFunc.apply(rows.unflatten(-1, (3, h, d)), cu, max_len, p_drop, None, causal, False)
+    rng = out_unpad.grad_fn.rng_state
+    assert rng is not None and rng.shape == (2,) and rng.dtype == torch.int64
+    out = pad_input(out_unpad.flatten(1), indices, batch, seqlen).unflatten(-1, (h, d))
+    g = torch.randn(batch, seqlen, h, d, generator=gen).to(dtype)
+    dqkv, = torch.autograd.grad(out, qkv, g.to(DEV))
+
+    seed, offset = (int(t) for t in rng.cpu())
+    keep = torch.from_numpy(P.attention_keep_mask(seed, offset, batch, h, seqlen, seqlen, p_drop))
+
+    def oracle(upcast, reorder):
+        t = x.clone().requires_grad_()
+        o = R.attention_fp32(t[:, :, 0], t[:, :, 1], t[:, :, 2], causal=causal, query_padding_mask=mask,
+                             key_padding_mask=mask, upcast=upcast, reorder_ops=reorder, dropout_p=p_drop,
+                             dropout_mask=keep)[0]
+        go, = torch.autograd.grad(o, t, g)
+        return o.detach(), go.masked_fill(~mask[:, :, None, None, None], 0.0)
+
+    o32, g32 = oracle(True, False)
+    o16, g16 = oracle(False, True)
+    err, base = (out.float().cpu() - o32.float()).abs().max().item(), (o16.float() - o32.float()).abs().max().item()
+    assert err <= 2 * base + 1e-5, ('out', err, base)
+    gerr = (dqkv.float().cpu() - g32.float()).abs().max().item()
+    gbase = (g16.float() - g32.float()).abs().max().item()
+    assert gerr <= 4 * gbase + 1e-4, ('dqkv', gerr, gbase)
+    assert torch.count_nonzero(out[~mask.to(DEV)]) == 0 and torch.count_nonzero(dqkv[~mask.to(DEV)]) == 0
+
+
+def test_flash_dropout_reproducible_and_state_dependent():
+    bp = _bp()
+    torch.manual_seed(4)
+    b, s, h, d = 2, 300, 4, 64
+    qkv = torch.randn(b * s, 3, h, d, device=DEV, dtype=torch.bfloat16)
+
+    def run(p, rng):
+        out = torch.empty_like(qkv[:, 0])
+        bp.flash_fwd(qkv[:, 0], qkv[:, 1], qkv[:, 2], out, None, None, s, s, 0.125, True, p, rng)
+        return out
+
+    a, a2, c = run(0.1, _state(1, 2)), run(0.1, _state(1, 2)), run(0.1, _state(1, 3))
+    assert torch.equal(a, a2) and not torch.equal(a, c)
+    assert torch.equal(run(0.0, None), run(0.0, _state(5, 6)))        # p = 0 ignores the state entirely
+    # E[dropout(P) / (1 - p)] = P: the mean over many states approaches the undropped output
+    mean = torch.zeros_like(a, dtype=torch.float32)
+    for i in range(64):
+        mean += run(0.1, _state(77, i)).float()
+    assert (mean / 64 - run(0.0, None).float()).abs().mean().item() < 0.02
+
+
+def test_mha_module_train_mode_uses_kernel_dropout():
+    """FlashSelfAttention in train() mode with attention_dropout > 0 (the reference trains Backpack with
+    GPT2Config's attn_pdrop = 0.1): runs, differs between calls, equals eval() when p = 0, backward works."""
+    from flash_attn.modules.mha import MHA
+    torch.manual_seed(0)
+    m = MHA(128, 2, causal=True, dropout=0.1, use_flash_attn=True).to(DEV, torch.bfloat16)
+    x = torch.randn(2, 96, 128, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    m.train()
+    y1, y2 = m(x), m(x)
+    assert not torch.equal(y1, y2)
+    y1.float().square().mean().backward()
+    assert x.grad is not None and torch.isfinite(x.grad.float()).all() and x.grad.abs().max() > 0
+    m.eval()
+    assert torch.equal(m(x), m(x))
+
+
+# ---------------------------------------------------------------------------------------------
+# fused dropout + add + LayerNorm: port of the reference's tests/ops/test_dropout_layer_norm.py::
+# test_dropout_layer_norm_training (no rowscale / colscale rows), its bounds: out and dx <= 4x, dgamma / dbeta <= 2x the
+# error of the same computation in plain PyTorch at the input dtype, all against fp32 (:100-114)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('has_residual', [True, False])
+@pytest.mark.parametrize('dropout_p', [0.37, 0.0])
+@pytest.mark.parametrize('weight_dtype', [torch.float32, torch.float16])
+@pytest.mark.parametrize('input_dtype,residual_dtype',
+                         [(torch.float16, torch.float16), (torch.float16, torch.float32),
+                          (torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16),
+                          (torch.bfloat16, torch.float32)])
+@pytest.mark.parametrize('hidden_size', [192, 384, 640, 768, 1024, 1600, 2048])
+def test_dropout_layer_norm_training(hidden_size, input_dtype, residual_dtype, weight_dtype, dropout_p, has_residual):
+    from flash_attn.ops.layer_norm import DropoutAddLayerNorm, dropout_add_layer_norm
+    if weight_dtype == torch.float16 and input_dtype == torch.bfloat16:
+        pytest.skip('not supported upstream either')
+    torch.random.manual_seed(0)
+    batch_size, seqlen = 8, 512
+    x0_pt = torch.randn(batch_size, seqlen, hidden_size, device=DEV, dtype=input_dtype, requires_grad=True)
+    x0 = x0_pt.detach().clone().requires_grad_()
+    x0_ref = x0_pt.detach().clone().float().requires_grad_()
+    if has_residual:
+        x1_pt = torch.randn_like(x0, dtype=residual_dtype, requires_grad=True)
+        x1 = x1_pt.detach().clone().requires_grad_()
+        x1_ref = x1_pt.detach().clone().float().requires_grad_()
+    else:
+        x1 = None
+    model_pt = torch.nn.LayerNorm(hidden_size, device=DEV, dtype=weight_dtype)
+    torch.nn.init.normal_(model_pt.weight)
+    torch.nn.init.normal_(model_pt.bias)
+    model_ref = torch.nn.LayerNorm(hidden_size, device=DEV, dtype=torch.float32)
+    model = DropoutAddLayerNorm(hidden_size, p=dropout_p, device=DEV, dtype=weight_dtype)
+    with torch.no_grad():
+        model.weight.copy_(model_pt.weight)
+        model.bias.copy_(model_pt.bias)
+        model_ref.weight.copy_(model_pt.weight)
+        model_ref.bias.copy_(model_pt.bias)
+    residual_in_fp32 = (not has_residual) and residual_dtype == torch.float32
+    out, dmask = dropout_add_layer_norm(x0, x1, model.weight, model.bias, model.p, model.epsilon,
+                                        residual_in_fp32=residual_in_fp32, return_dropout_mask=True)
+    assert out.dtype == input_dtype and dmask.dtype == torch.uint8 and dmask.shape == x0.shape
+    frac = 1 - dmask.float().mean().item()
+    assert abs(frac - dropout_p) < 0.005, frac
+    # the mask the kernel reports is the documented function of the generator state it drew
+    if dropout_p > 0 and hidden_size <= 768:
+        seed, offset = (int(t) for t in out.grad_fn.rng_state.cpu())
+        want = P.rows_keep_mask(seed, offset, 64, hidden_size, dropout_p)
+        assert np.array_equal(dmask.flatten(0, 1)[:64].cpu().numpy().astype(bool), want)
+    if has_residual:
+        residual_pt = ((x0_pt.float() * dmask.float()) / (1 - dropout_p) + x1_pt.float()).to(dtype=residual_dtype)
+        residual_ref = (x0_ref * dmask.float()) / (1 - dropout_p) + x1_ref
+    else:
+        residual_pt = ((x0_pt.float() * dmask.float()) / (1 - dropout_p)).to(dtype=residual_dtype)
+        residual_ref = (x0_ref * dmask.float()) / (1 - dropout_p)
+    out_pt = model_pt(residual_pt.to(dtype=weight_dtype)).to(dtype=input_dtype)
+    out_ref = model_ref(residual_ref)
+    assert (out - out_ref).abs().max() <= 4 * (out_pt - out_ref).abs().max() + 1e-4
+
+    g = torch.randn_like(out) / batch_size
+    out_pt.backward(g)
+    out.backward(g)
+    out_ref.backward(g)
+    assert (x0.grad - x0_ref.grad).abs().max() <= 4 * (x0_pt.grad - x0_ref.grad).abs().max() + 1e-4
+    if has_residual:
+        assert (x1.grad - x1_ref.grad).abs().max() <= 4 * (x1_pt.grad - x1_ref.grad).abs().max() + 1e-4
+    assert (model.weight.grad - model_ref.weight.grad).abs().max() <= \\
+        2 * (model_pt.weight.grad - model_ref.weight.grad).abs().max() + 3e-5
+    assert (model.bias.grad - model_ref.bias.grad).abs().max() <= \\
+        2 * (model_pt.bias.grad - model_ref.bias.grad).abs().max() + 3e-5
+
+
+def test_backpack_train_mode_with_the_reference_dropout_defaults_under_autocast():
+    """The reference's training recipe on the HIP path: GPT2Config's default attn / resid / embd dropout 0.1
+    (training/configs/experiment/owt/backpack-small-flash.yaml overrides none), fp32 parameters under autocast
+    (trainer precision 16), fused flags on.  One forward + backward in train() mode: runs in-kernel dropout in
+    attention and in every fused LayerNorm (fp32 embedding output into the first one), finite loss and gradients
+    for every parameter; eval() after it is deterministic."""
+    from flash_attn.losses.cross_entropy import CrossEntropyLoss
+    from src.models.backpack import BackpackConfig, BackpackLMHeadModel
+    torch.manual_seed(11)
+    cfg = BackpackConfig(n_embd=128, n_head=2, n_layer=2, num_content_vectors=4, vocab_size=512, n_positions=128,
+                         scale_attn_by_inverse_layer_idx=True, pad_vocab_size_multiple=8, use_flash_attn=True,
+                         fused_dropout_add_ln=True, fused_dense_gelu_dense=True, fused_bias_fc=True)
+    assert cfg.attn_pdrop == cfg.resid_pdrop == cfg.embd_pdrop == 0.1
+    model = BackpackLMHeadModel(cfg).to(DEV).train()           # fp32 parameters
+    ids = torch.randint(0, 512, (4, 128), device=DEV)
+    labels = torch.randint(0, 512, (4 * 128,), device=DEV)
+    losses = []
+    for _ in range(2):
+        model.zero_grad()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            logits = model(ids).logits
+        loss = CrossEntropyLoss()(logits.flatten(0, 1).float(), labels)
+        loss.backward()
+        losses.append(loss.item())
+        for name, prm in model.named_parameters():
+            assert prm.grad is not None and torch.isfinite(prm.grad).all(), name
+    assert all(math.isfinite(x) for x in losses) and losses[0] != losses[1]      # different masks per step
+    model.eval()
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+        a, b = model(ids).logits, model(ids).logits
+    assert torch.equal(a, b)

@@ -147,9 +147,12 @@ def test_hip_branch_never_falls_back():
     assert model.transformer.use_hip and model.transformer.contextualization_attn.use_hip
     with pytest.raises((AssertionError, RuntimeError)):
         model(torch.zeros(1, 8, dtype=torch.long))
-    with pytest.raises(RuntimeError, match='dropout'):
+    with pytest.raises(RuntimeError, match='GPU'):     # dropout included: in-kernel or nothing
         fai._flash_attn_forward(qkv[0, :, 0], qkv[0, :, 1], qkv[0, :, 2], qkv[0, :, 0].clone(),
                                 None, None, 8, 8, 0.1, 0.2, True, False)
+    with pytest.raises(RuntimeError, match='dropout_p'):
+        fai._flash_attn_forward(qkv[0, :, 0], qkv[0, :, 1], qkv[0, :, 2], qkv[0, :, 0].clone(),
+                                None, None, 8, 8, 1.0, 0.2, True, False)
     assert FlashMHA(64, 2).head_dim == 32
 
 
