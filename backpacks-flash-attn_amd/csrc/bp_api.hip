@@ -44,16 +44,10 @@ inline bool env_is(const char *name, const char *value) {
 inline bool dev_force_staged_flash() { static const bool v = env_is("BP_FLASH_IMPL", "staged"); return v; }
 inline bool dev_force_staged_mix() { static const bool v = env_is("BP_MIX_IMPL", "staged"); return v; }
 inline bool dev_flash_pair() { static const bool v = !env_is("BP_FLASH_PAIR", "0"); return v; }
-inline int dev_mix_order() {
-    static const int v = env_is("BP_MIX_ORDER", "grouped") ? 0 : env_is("BP_MIX_ORDER", "lockstep") ? 2
-                       : env_is("BP_MIX_ORDER", "hybrid") ? 3 : 1;
-    return v;
-}
 #else
 inline bool dev_force_staged_flash() { return false; }
 inline bool dev_force_staged_mix() { return false; }
 inline bool dev_flash_pair() { return true; }
-inline int dev_mix_order() { return 1; }
 #endif
 
 // 16-byte friendly shapes take the LDS-DMA ring kernel; anything else (odd head dims, unaligned
@@ -302,8 +296,6 @@ int bp_sense_mix_weighted(const void *qk, const void *content, const float *key_
     p.b = batch; p.s = seqlen; p.nsenses = nsenses; p.dk = d_k; p.dout = d_out;
     p.n_qtiles = (seqlen + 255) / 256;
     p.n_chunks = (d_out + 255) / 256;
-    // block -> (group, query tile) order, see sense_mix_dma.hip: heaviest tiles of all groups first
-    p.order = dev_mix_order();
     p.scale_log2e = softmax_scale * bp::kLog2e;
     const bool vec_qk = (d_k % 8 == 0) && aligned16(p.q) && aligned16(p.k) && mult8(qk_batch_stride) &&
                         mult8(qk_row_stride) && mult8(qk_sense_stride);
@@ -311,7 +303,7 @@ int bp_sense_mix_weighted(const void *qk, const void *content, const float *key_
                        mult8(c_row_stride) && mult8(c_sense_stride) && mult8(o_batch_stride) &&
                        mult8(o_row_stride);
     hipError_t e;
-    if (vec_qk && vec_c && !dev_force_staged_mix()) e = bp::launch_sense_mix_dma(p, dtype, st);
+    if (vec_qk && vec_c && p.n_qtiles <= 256 && !dev_force_staged_mix()) e = bp::launch_sense_mix_dma(p, dtype, st);
     else e = bp::launch_sense_mix(p, dtype, vec_qk, vec_c, st);
     return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
 }

@@ -61,6 +61,13 @@ struct ProbsParams {
     uint32_t drop_thr;
 };
 
+// job queues of the persistent sense-mix launch (sense_mix_dma.hip): one ticket per XCD + an exit counter
+struct MixQueues {
+    unsigned int ticket[8];
+    unsigned int done;
+    unsigned int pad[7];
+};
+
 struct MixParams {
     const void *q, *k;        // q_l[t] = q + b*qk_bs + t*qk_rs + l*qk_ss ; k likewise
     const void *c;            // content[b, s, l, :] = c + b*c_bs + s*c_rs + l*c_ss
@@ -75,8 +82,8 @@ struct MixParams {
     int b, s, nsenses, dk, dout;
     int n_qtiles;             // ceil(s / 256)
     int n_chunks;             // ceil(dout / 256)
-    int order;                // work order: 0 = all query tiles of a group adjacent, 1 = heaviest tiles of ALL groups first
     float scale_log2e;
+    MixQueues *queues;        // filled in by launch_sense_mix_dma
 };
 
 struct SoftmaxBwdParams {

@@ -151,27 +151,38 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
             v_voff[j] = (uint32_t)(row * p.v_rs + v_col[j]) * 2u;
         }
     }
-    // Full tiles: scalar base (+= 64 rows per tile) + constant per-lane byte offset -> no VALU at all.
-    // The last, partial tile clamps its rows to the final valid one (those keys are masked later).
-    auto issue = [&](int kb) {
-        const uint32_t stage = lds0 + (kb & 1) * C::STAGE;
-        const uint16_t *kt = kg + (int64_t)kb * C::BN * p.k_rs;
-        const uint16_t *vt = HAS_V ? vg + (int64_t)kb * C::BN * p.v_rs : nullptr;
-        const bool full = kb * C::BN + C::BN <= seq_k;
+    // Scalar tile base + constant per-lane byte offset -> no VALU at all.  The only partial tile a sweep can meet is
+    // the sequence's last one; its rows are clamped to the final valid key (those keys are masked later) through a
+    // second, precomputed offset set and a uniform select.
+    const int kb_partial = (seq_k % C::BN) != 0 ? seq_k / C::BN : -1;
+    const int last_row = seq_k - 1 - (seq_k / C::BN) * C::BN;
+    uint32_t k_voff_p[C::K_DMA], v_voff_p[HAS_V ? C::V_DMA : 1];
 #pragma unroll
-        for (int j = 0; j < C::K_DMA; ++j) {
-            uint32_t off = k_voff[j];
-            if (!full) off = (uint32_t)(min(k_row[j], seq_k - 1 - kb * C::BN) * p.k_rs + k_col[j]) * 2u;
-            if (FULLD || k_col[j] < p.d) dma16_s(kt, off, stage + (wave * C::K_DMA + j) * 1024);
-        }
+    for (int j = 0; j < C::K_DMA; ++j) k_voff_p[j] = (uint32_t)(min(k_row[j], last_row) * p.k_rs + k_col[j]) * 2u;
+    if (HAS_V) {
+#pragma unroll
+        for (int j = 0; j < C::V_DMA; ++j) v_voff_p[j] = (uint32_t)(min(v_row[j], last_row) * p.v_rs + v_col[j]) * 2u;
+    }
+    const int64_t k_tile_stride = (int64_t)C::BN * p.k_rs, v_tile_stride = (int64_t)C::BN * p.v_rs;
+    const uint16_t *kt = kg, *vt = vg;   // tile kb of the NEXT issue (tiles are issued in order 0, 1, 2, ...)
+    auto issue = [&](int kb) {
+        // (readfirstlane: inside the per-lane predicate of the !FULLD case hipcc may hold the uniform address in a VGPR)
+        const uint32_t stage = __builtin_amdgcn_readfirstlane(lds0 + (kb & 1) * C::STAGE);
+        const bool partial = kb == kb_partial;
+#pragma unroll
+        for (int j = 0; j < C::K_DMA; ++j)
+            if (FULLD || k_col[j] < p.d)
+                dma16_s(kt, partial ? k_voff_p[j] : k_voff[j],
+                        __builtin_amdgcn_readfirstlane(stage + (wave * C::K_DMA + j) * 1024));
         if (HAS_V) {
 #pragma unroll
-            for (int j = 0; j < C::V_DMA; ++j) {
-                uint32_t off = v_voff[j];
-                if (!full) off = (uint32_t)(min(v_row[j], seq_k - 1 - kb * C::BN) * p.v_rs + v_col[j]) * 2u;
-                if (FULLD || v_col[j] < p.d) dma16_s(vt, off, stage + C::KTILE + (wave * C::V_DMA + j) * 1024);
-            }
+            for (int j = 0; j < C::V_DMA; ++j)
+                if (FULLD || v_col[j] < p.d)
+                    dma16_s(vt, partial ? v_voff_p[j] : v_voff[j],
+                            __builtin_amdgcn_readfirstlane(stage + C::KTILE + (wave * C::V_DMA + j) * 1024));
+            vt += v_tile_stride;
         }
+        kt += k_tile_stride;
     };
 
     f32x16 acc[HAS_V ? NV : 1];
@@ -259,7 +270,9 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
         // visible key of my row -> ONE per-lane limit against compile-time constants
         int last = seq_k - 1;
         if (p.causal) last = min(last, my_q);
-        const int lim = last - kb * C::BN - 4 * hh;
+        int lim = last - kb * C::BN - 4 * hh;
+        // (opaque on purpose: otherwise hipcc speculates the 32 compares out of this rarely taken branch into every tile)
+        asm volatile("" : "+v"(lim));
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll

@@ -2,40 +2,33 @@
 //
 //     out[b,t,:] = sum_l sum_{s<=t} exp(scale * q_l[t].k_l[s] - lse[b,l,t]) * C[b,s,l,:]
 //
-// Same contraction and tile algebra as sense_mix.hip (see there and bp_common.h); what changes is how
-// the K_l / C_l tiles reach LDS.  The register-staged kernel prefetches ONE 32-key tile ahead and is
-// latency-bound (rocprof r01_a: 61 % of wave cycles in s_waitcnt, L2 hit rate 15 %: four query
-// tiles sweep the same C at different speeds, so most tiles come from HBM / Infinity Cache).  Here
-//   * tiles are 64 keys (40 KB: 32 KB of C + 8 KB of K) in a 3-slot LDS ring (120 KB, one workgroup
-//     per CU), filled by `global_load_lds_dwordx4` (no VGPR round trip, no ds_write pass);
-//   * two tiles are always in flight (>= 2 us of HBM latency covered by >= 76 MFMAs per SIMD);
-//   * waits are COUNTED: each wave issues exactly DMA_PER_STAGE DMA instructions per tile, so
-//     `s_waitcnt vmcnt(DMA_PER_STAGE)` = "my share of the oldest tile has landed", then ONE raw
-//     `s_barrier` per tile makes every wave's share visible and retires the slot read last step;
-//   * the DMA writes LDS linearly (wave base + lane*16), so the XOR swizzles that make ds_read_b128
-//     (K) and ds_read_b64_tr_b16 (C) conflict-free are applied to the per-lane SOURCE address.
-// Default loop order: sense outer, 64-key tile inner; blocks dispatched heaviest query tiles first.
-// Alternative kept behind -DBP_MIX_SUPER=1 (+ BP_MIX_ORDER=lockstep): key SUPER-tile (256 keys) outer,
-// sense middle, 64-key tile inner, for KD <= 4.  MEASURED (r01_d, B=64 S=1024 k=16 d=768): it does what
-// it was built for -- HBM traffic 5.7 GB -> 2.1 GB per launch, L2 hit rate 18 % -> 74 % -- and is still
-// SLOWER: 1.82 ms (lockstep groups) / 1.49 ms (heaviest-first) against 1.39 ms for this default.  The
-// LDS-DMA fill itself reaches 130 GB/s per CU out of L2 but only 25 GB/s per CU (6.4 TB/s chip) out of
-// HBM (scripts/probes/dma_rate.hip), the default order needs ~0.9 ms of pure HBM time per launch, and
-// the compute stream alone takes 1.0 ms ("no DMA" ablation) -- yet whole-group dispatch loses more to
-// its tail and to all CUs of an XCD pulling the same lines at once than the saved traffic returns.
-// How the alternative works:
-// key SUPER-tile (256 keys) outer, sense middle, 64-key tile inner.
-// The query tiles of one (batch, column chunk) group then walk C in the same order at the same pace
-// (a step costs the same for every tile; tile t merely stops after super-tile t), so when they are
-// co-resident on one XCD the group pulls each C tile from HBM once and the others hit L2 -- with the
-// old sense-outer order the four tiles swept C at different speeds and re-streamed it 2.5x
-// (rocprof r01_c: 5.98 GB per launch against 1.91 GB algorithmic).  Memory locality improves too: one
-// super-tile is a contiguous 6 MB slab of the (B,S,k,d) buffer.  The price is 4x more sense switches;
-// the per-sense operands of a wave (its 32 query fragments and their log-sum-exp) therefore arrive
-// through a per-wave LDS "mailbox" filled by the same DMA queue one step ahead (the lane that DMAs
-// a fragment is the lane that reads it back), so a switch costs KD+1 ds_reads and no vmcnt drain.
-// Rows past the sequence are fetched from a clamped (valid) row: their probabilities are exactly 0
-// by the causal mask and 0 * finite = 0; LDS is zeroed once so never-written pad slots are 0.
+// Same contraction and tile algebra as sense_mix.hip (see there and bp_common.h).  One workgroup = 8 waves
+// = 256 queries x 256 output columns of one sample; sense outer, 64-key tile inner; a pipeline step = one
+// (sense, key tile): S^T (KD MFMAs per 32 keys) -> P^T = exp2(S^T c - lse) -> O^T += C^T P^T (16 MFMAs per
+// 32 keys), probabilities final on first touch thanks to the LSE pre-pass.
+//   * tiles are 64 keys (40 KB: 32 KB of C + 8 KB of K) in a 3-slot LDS ring (120 KB, one workgroup per CU),
+//     filled by `global_load_lds_dwordx4` (no VGPR round trip, no ds_write pass), two tiles always in flight,
+//     COUNTED waits + ONE raw s_barrier per tile (bp_dma.h); the XOR swizzles that make ds_read_b128 (K) and
+//     ds_read_b64_tr_b16 (C) conflict-free are applied to the per-lane SOURCE address.  Every lane of every
+//     DMA piece moves VALID data (pad slots receive a duplicate of column 0): K pad columns meet zero Q columns,
+//     C pad columns feed output columns that are never stored, so nothing is predicated and nothing is zeroed.
+//   * the two waves of a SIMD leave the tile barrier together, so without care both sit in their softmax
+//     (VALU, matrix pipe idle) and then both in their 16 MFMAs (VALU idle) at the same time -- a lone workgroup
+//     measured 49 % MFMA utilisation that way (r02_a).  The steady-state step therefore software-pipelines
+//     inside the wave: both S^T halves first, softmax of half 0, then the 16 MFMAs of half 0 are issued WITH the
+//     softmax of half 1 between them (independent registers, one basic block: no branch, no predicated DMA).
+//     Steps that touch the diagonal (some waves dead or masking) keep the simple per-half form.
+//   * PERSISTENT launch: one workgroup per CU pulls (group, query tile) jobs from 8 per-XCD queues, heaviest
+//     query tiles first, stealing from the other queues when its own is empty.  The hardware dispatcher places
+//     workgroups in order and round-robin: with one workgroup per CU and jobs of 4,3,2,1 units that gave rounds of
+//     4+3+2 = 9 units per CU against 7.5 ideal (dispatch_order probe); a static snake assignment lost
+//     to run-time variance (r01).  A group's tiles still prefer one XCD, i.e. one L2 holds its C tiles.
+//     Queue state: 64 bytes of device memory from a small ring owned by the library (self-resetting: the last
+//     workgroup to leave zeroes it), see launch_sense_mix_dma.
+// Rows past the sequence are fetched from a clamped (valid) row: their probabilities are exactly 0 by the
+// causal mask and 0 * finite = 0.
+#include <atomic>
+
 #include "bp_common.h"
 #include "bp_dma.h"
 #include "bp_kernels.h"
@@ -56,20 +49,15 @@ struct MixDmaCfg {
     static constexpr int C_DMA = CTILE / 1024 / NWAVE;   // 4
     static constexpr int DMA_PER_STAGE = K_DMA + C_DMA + (WEIGHTED ? 1 : 0);
     static constexpr int K_ROWS_PER_DMA = 1024 / KROW;   // 8 or 4
-#ifndef BP_MIX_SUPER
-#define BP_MIX_SUPER 0   // measured slower on MI355X (see the header comment); kept as an A/B build switch
-#endif
-    static constexpr bool SUPER = BP_MIX_SUPER && KD <= 4;   // super-tile loop order + Q mailbox (LDS budget)
-    static constexpr int SUP = BM / BK;                  // key tiles per super-tile
-    static constexpr int QBOX_WAVE = KD * 1024 + 256;    // KD fragments (64 lanes x 16 B) + 64 x lse
-    static constexpr int QBOX_OFF = NSTAGE * STAGE;
-    static constexpr int SMEM = QBOX_OFF + (SUPER ? NWAVE * QBOX_WAVE : 0);
+    static constexpr int JOB_OFF = NSTAGE * STAGE;       // 16 bytes: job broadcast
+    static constexpr int SMEM = JOB_OFF + 16;
 };
 
-// Position of a pipeline step: super-tile, sense, key tile inside the super-tile.
-struct MixCursor {
-    int st, l, kk;
-};
+// jobs of queue q: groups g = q, q+8, ... ; heaviest query tile first
+BP_DEV int mix_queue_groups(const MixParams &p, int q) {
+    const int ngroups = p.b * p.n_chunks;
+    return ngroups > q ? (ngroups - q + 7) / 8 : 0;
+}
 
 template <class ET, int KD, bool FULL, bool WEIGHTED>
 __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
@@ -82,154 +70,32 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31;
     const int hh = lane >> 5;
-
-    int grp, slot;
-    if (p.order >= 2) {
-        // Per XCD: whole (batch, chunk) groups, heaviest tile first inside a group, the column chunks of
-        // one batch next to each other (same K tiles, adjacent pieces of the same C rows).  The query
-        // tiles of a group then start together and walk C in lockstep -> one HBM read per group, the rest
-        // L2 hits.  In-order dispatch of whole groups leaves a long tail though (the last group's
-        // heaviest tile starts last), so with order 3 only the first 2/3 of an XCD's groups go out this
-        // way and the rest heaviest-tiles-first: same makespan as pure heaviest-first in a list-scheduling
-        // model (8.0 vs the 7.5 ideal for 24 groups on 32 CUs; pure groups: 10.0), ~40 % less C traffic.
-        const int xcd = blockIdx.x & 7;
-        const int s8 = blockIdx.x >> 3;
-        const int gpx = ((p.b + 7) / 8) * p.n_chunks;           // groups per XCD
-        const int nq = p.order == 2 ? gpx : (2 * gpx) / 3;      // dispatched as whole groups
-        int j;
-        if (s8 < nq * p.n_qtiles) {
-            j = s8 / p.n_qtiles;
-            slot = s8 - j * p.n_qtiles;
-        } else {
-            const int r = s8 - nq * p.n_qtiles, rest = gpx - nq;
-            slot = r / rest;
-            j = nq + r - slot * rest;
-        }
-        const int bb = (j / p.n_chunks) * 8 + xcd;
-        if (bb >= p.b) return;
-        grp = bb * p.n_chunks + (j % p.n_chunks);
-    } else if (p.order == 0) {
-        if (!xcd_map(blockIdx.x, p.b * p.n_chunks, p.n_qtiles, grp, slot)) return;
-    } else {
-        // heaviest query tiles of every group first (list scheduling with the longest jobs first),
-        // a group still always lands on the same XCD
-        const int ngroups = p.b * p.n_chunks;
-        const int per_xcd = (ngroups + 7) / 8;
-        const int s8 = blockIdx.x >> 3;
-        slot = s8 / per_xcd;
-        grp = (s8 - slot * per_xcd) * 8 + (blockIdx.x & 7);
-        if (grp >= ngroups) return;
-    }
-    const int qt = p.n_qtiles - 1 - slot;
-    const int batch = grp / p.n_chunks;
-    const int chunk = grp - batch * p.n_chunks;
-    const int col_base = chunk * C::BNC;
     const int S = p.s;
-
-    const uint16_t *qg = reinterpret_cast<const uint16_t *>(p.q) + batch * p.qk_bs;
-    const uint16_t *kg = reinterpret_cast<const uint16_t *>(p.k) + batch * p.qk_bs;
-    const uint16_t *cg = reinterpret_cast<const uint16_t *>(p.c) + batch * p.c_bs;
-
-    const int k_end = min(S, qt * C::BM + C::BM);
-    const int nkb = (k_end + C::BK - 1) / C::BK;
-    const int nsteps = p.nsenses * nkb;
-    // steps are ordered (super-tile, sense, tile); without SUPER there is one super-tile of nkb tiles
-    const int sup = C::SUPER ? C::SUP : nkb;
-    const int n_super = (nkb + sup - 1) / sup;
-    const int nkb_last = nkb - sup * (n_super - 1);
-    auto advance = [&](MixCursor &c) {
-        if (++c.kk == (c.st + 1 < n_super ? sup : nkb_last)) {
-            c.kk = 0;
-            if (++c.l == p.nsenses) { c.l = 0; ++c.st; }
-        }
-    };
-
-    const int q0 = qt * C::BM + wave * 32;
-    const int my_q = q0 + l31;
-    const int my_q_clamped = min(my_q, S - 1);
-    const bool wave_has_rows = q0 < S;
-    const int my_diag_sub = q0 >> 5;   // index of the 32-key sub-block that holds my diagonal
     const float c2 = p.scale_log2e;
-    const int nb_live = FULL ? C::NB : min(C::NB, (p.dout - col_base + 31) / 32);
+    const uint32_t lds0 = lds_base_addr(smem);
 
-    // ---- zero the ring once: pad slots that no DMA ever writes must read as 0 -----------------------
-    {
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        for (int off = tid * 16; off < C::SMEM; off += C::NT * 16) lds_write_16B(smem, off, z);
-    }
-    __syncthreads();
-
-    // ---- per-lane DMA source descriptors (tile-invariant parts) ------------------------------------
+    // ---- per-lane DMA source descriptors, job-invariant parts ------------------------------------------
     // K piece j of this wave: rows (wave*K_DMA + j)*RPD + lane/KSLOTS, stored slot lane%KSLOTS
-    int k_row[C::K_DMA], k_col[C::K_DMA];
-    bool k_on[C::K_DMA];
+    int k_row[C::K_DMA];
+    uint32_t k_col[C::K_DMA];
 #pragma unroll
     for (int j = 0; j < C::K_DMA; ++j) {
         const int row = (wave * C::K_DMA + j) * C::K_ROWS_PER_DMA + lane / C::KSLOTS;
         const int logical = (lane % C::KSLOTS) ^ k_swz<C::KROW>(row);
         k_row[j] = row;
-        k_col[j] = logical * 8;
-        k_on[j] = logical * 8 < p.dk;
+        k_col[j] = logical * 8 < p.dk ? logical * 8 : 0;   // pad slot: a duplicate of column 0 (finite)
     }
     // C piece j of this wave: rows (wave*C_DMA + j)*2 + lane/32, stored chunk lane%32
-    int c_row[C::C_DMA], c_col[C::C_DMA];
-    bool c_on[C::C_DMA];
+    int c_row[C::C_DMA];
+    uint32_t c_col[C::C_DMA];
 #pragma unroll
     for (int j = 0; j < C::C_DMA; ++j) {
         const int row = (wave * C::C_DMA + j) * 2 + (lane >> 5);
         const int stored = lane & 31;
         const int logical = (((stored >> 2) ^ (row & 3)) << 2) | (stored & 3);
         c_row[j] = row;
-        c_col[j] = col_base + logical * 8;
-        c_on[j] = c_col[j] < p.dout;
+        c_col[j] = logical * 8;
     }
-
-    const uint32_t lds0 = lds_base_addr(smem);
-    // DMA piece `j` (0 .. DMA_PER_STAGE-1: the K pieces, then the C pieces) of pipeline step `step`
-    auto issue_piece = [&](int step, const MixCursor &c, int j) {
-        const int l = c.l;
-        const int kb = c.st * sup + c.kk;
-        const uint32_t stage_off = lds0 + (step % C::NSTAGE) * C::STAGE;
-        if (j < C::K_DMA) {
-            const int key = min(kb * C::BK + k_row[j], S - 1);
-            const uint16_t *src = kg + (int64_t)l * p.qk_ss + (int64_t)key * p.qk_rs + k_col[j];
-            if (k_on[j]) dma16_d(src, stage_off + (wave * C::K_DMA + j) * 1024);
-        } else if (WEIGHTED && j == C::K_DMA + C::C_DMA) {
-            // key weights of this (sense, tile): lane i fetches w[key0 + i] into the wave's own 256-B slot
-            const float *src = p.kw + batch * p.kw_bs + (int64_t)l * p.kw_ss + min(kb * C::BK + lane, S - 1);
-            dma4(src, stage_off + C::KTILE + C::CTILE + wave * 256);
-        } else {
-            const int jc = j - C::K_DMA;
-            const int key = min(kb * C::BK + c_row[jc], S - 1);
-            const uint16_t *src = cg + (int64_t)l * p.c_ss + (int64_t)key * p.c_rs + c_col[jc];
-            if (c_on[jc]) dma16_d(src, stage_off + C::KTILE + (wave * C::C_DMA + jc) * 1024);
-        }
-    };
-    auto issue = [&](int step, const MixCursor &c) {
-#pragma unroll
-        for (int j = 0; j < C::DMA_PER_STAGE; ++j) issue_piece(step, c, j);
-    };
-    // Inside the main loop the pieces of tile step+2 are NOT issued in one burst after the barrier
-    // (eight waves x five 1-KiB requests at once back up the CU's vector-memory issue path, and every
-    // wave sits in that queue: ablation r01_d, "no DMA" = -33 % time) but in SLOTS spread over the step,
-    // each one behind a group of MFMAs that keeps the matrix pipe busy while the request issues.
-    constexpr int N_SLOTS = 5;
-    auto issue_slot = [&](int step, const MixCursor &c, int slot) {
-#if !defined(BP_ABL_MIX_NOSYNC) && !defined(BP_ABL_MIX_NODMA)
-        if (step < nsteps) {
-#pragma unroll
-            for (int j = 0; j < C::DMA_PER_STAGE; ++j)
-                if (j * N_SLOTS / C::DMA_PER_STAGE == slot) issue_piece(step, c, j);
-        }
-#endif
-    };
-
-    f32x16 acc[C::NB];
-#pragma unroll
-    for (int n = 0; n < C::NB; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-
     // lane-constant LDS read offsets
     int k_read_off[KD];   // K fragment (A operand of S^T): row l31 (+32*kk), logical slot 2*s + hh
 #pragma unroll
@@ -238,30 +104,121 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
     // (k_swz only looks at row bits 0..3, so +32 rows keeps the same swizzle)
     const int c_row_lane = 4 * hh + ((lane & 15) >> 2);
     const int c_ch_lane = ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1);
-    int c_read_off[C::NB];   // C^T fragment: (row c_row_lane, 16-col group of block n), +8 rows keeps swizzle
+    // C^T fragment: (row c_row_lane, 16-col group of block n), +8 rows keeps swizzle.  The swizzle XORs the 64-B chunk
+    // index n with row & 3, i.e. only its low two bits: block n + 4 sits exactly 256 bytes after block n, so four
+    // lane offsets + an immediate serve the eight blocks.
+    static_assert(C::NB == 8, "c_read_off assumes 8 column blocks");
+    int c_read_off[4];
 #pragma unroll
-    for (int n = 0; n < C::NB; ++n) c_read_off[n] = v_lds_off<C::NB>(c_row_lane, n * 4 + c_ch_lane) + (lane & 1) * 8;
+    for (int n = 0; n < 4; ++n) c_read_off[n] = v_lds_off<C::NB>(c_row_lane, n * 4 + c_ch_lane) + (lane & 1) * 8;
 
-    u32x4 qf[KD];
-    float lse2 = 0.f;
-
-    // per-sense operands of this wave: my query's fragments (B operand of S^T = K Q^T) and its LSE
-    const int qbox = C::QBOX_OFF + wave * C::QBOX_WAVE;
-    auto issue_q = [&](int l) {   // SUPER: into the mailbox, through the DMA queue
-        const uint16_t *row = qg + (int64_t)my_q_clamped * p.qk_rs + (int64_t)l * p.qk_ss;
-#pragma unroll
-        for (int s = 0; s < KD; ++s) {
-            const int col = 16 * s + 8 * hh;
-            if (col < p.dk) dma16_d(row + col, lds0 + qbox + s * 1024);
+    // ---- job queues -------------------------------------------------------------------------------------
+    MixQueues *queues = p.queues;
+    uint32_t exhausted = 0;   // bit q: queue q has no jobs left (wave-uniform, only thread 0 uses it)
+    const int my_xcd = blockIdx.x & 7;
+    auto next_job = [&]() -> int {   // thread 0 only; returns grp * 256 + qt, or -1
+        for (int t = 0; t < 8; ++t) {
+            const int q = (my_xcd + t) & 7;
+            if (exhausted & (1u << q)) continue;
+            const int groups = mix_queue_groups(p, q);
+            const int njobs = groups * p.n_qtiles;
+            const int idx = njobs > 0 ? (int)atomicAdd(&queues->ticket[q], 1u) : njobs;
+            if (idx < njobs) {
+#ifdef BP_MIX_HEAVY_FIRST   // all groups' heaviest tiles first (measured against the default in r02_e)
+                const int slot = idx / groups;
+                const int grp = (idx - slot * groups) * 8 + q;
+#else                       // a group's tiles together, heaviest first: its C slab is re-read while still cached
+                const int gl = idx / p.n_qtiles;
+                const int slot = idx - gl * p.n_qtiles;
+                const int grp = gl * 8 + q;
+#endif
+                return grp * 256 + (p.n_qtiles - 1 - slot);
+            }
+            exhausted |= 1u << q;
         }
-        dma4(p.lse + ((int64_t)batch * p.nsenses + l) * p.lse_stride + my_q_clamped, lds0 + qbox + KD * 1024);
+        return -1;
     };
-    auto take_q = [&](int l) {
-        if constexpr (C::SUPER) {
+
+    for (;;) {
+        __syncthreads();   // every wave is done with the previous job's ring (and has read its job word)
+        if (tid == 0) *reinterpret_cast<int *>(smem + C::JOB_OFF) = next_job();
+        __syncthreads();
+        const int job = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(smem + C::JOB_OFF));
+        if (job < 0) break;
+        const int grp = job >> 8, qt = job & 255;
+        const int batch = grp / p.n_chunks;
+        const int chunk = grp - batch * p.n_chunks;
+        const int col_base = chunk * C::BNC;
+
+        const uint16_t *qg = reinterpret_cast<const uint16_t *>(p.q) + batch * p.qk_bs;
+        const uint16_t *kg = reinterpret_cast<const uint16_t *>(p.k) + batch * p.qk_bs;
+        const uint16_t *cg = reinterpret_cast<const uint16_t *>(p.c) + batch * p.c_bs;
+
+        const int k_end = min(S, qt * C::BM + C::BM);
+        const int nkb = (k_end + C::BK - 1) / C::BK;
+        const int nsteps = p.nsenses * nkb;
+        // key tiles below this index are full and entirely visible to every row of the workgroup
+        const int nkb_clean = WEIGHTED ? 0 : min((qt * C::BM) / C::BK, S / C::BK);
+
+        const int q0 = qt * C::BM + wave * 32;
+        const int my_q = q0 + l31;
+        const int my_q_clamped = min(my_q, S - 1);
+        const bool wave_has_rows = q0 < S;
+        const int my_diag_sub = q0 >> 5;   // index of the 32-key sub-block that holds my diagonal
+        const int nb_live = FULL ? C::NB : min(C::NB, (p.dout - col_base + 31) / 32);
+
+        // per-lane byte offsets of my pieces inside a tile (the scalar tile base is added by the DMA instruction):
+        // one set for full tiles, one for the job's only possible partial tile (the last one, when the sequence
+        // ends inside it; its rows are clamped to the final valid key).  A uniform select per piece, no branch.
+        const int kb_partial = (k_end == S && (S % C::BK) != 0) ? nkb - 1 : -1;
+        const int last_row = S - 1 - (nkb - 1) * C::BK;
+        uint32_t k_voff[C::K_DMA], c_voff[C::C_DMA], k_voff_p[C::K_DMA], c_voff_p[C::C_DMA];
 #pragma unroll
-            for (int s = 0; s < KD; ++s) qf[s] = lds_read_16B(smem, qbox + s * 1024 + lane * 16);
-            lse2 = *reinterpret_cast<const float *>(smem + qbox + KD * 1024 + lane * 4) * kLog2e;
-        } else {
+        for (int j = 0; j < C::K_DMA; ++j) {
+            k_voff[j] = (uint32_t)(k_row[j] * p.qk_rs + k_col[j]) * 2u;
+            k_voff_p[j] = (uint32_t)(min(k_row[j], last_row) * p.qk_rs + k_col[j]) * 2u;
+        }
+#pragma unroll
+        for (int j = 0; j < C::C_DMA; ++j) {
+            const uint32_t col = (FULL || col_base + (int)c_col[j] < p.dout) ? col_base + c_col[j] : col_base;
+            c_voff[j] = (uint32_t)(c_row[j] * p.c_rs + col) * 2u;
+            c_voff_p[j] = (uint32_t)(min(c_row[j], last_row) * p.c_rs + col) * 2u;
+        }
+
+        // DMA pieces of pipeline step (l, kb) into ring slot `slot`; `pieces` selects a subset (bit j)
+        auto issue = [&](int l, int kb, int slot, uint32_t pieces) {
+            const uint32_t stage_off = lds0 + slot * C::STAGE;
+            const uint16_t *kt = kg + (int64_t)l * p.qk_ss + (int64_t)kb * C::BK * p.qk_rs;
+            const uint16_t *ct = cg + (int64_t)l * p.c_ss + (int64_t)kb * C::BK * p.c_rs;
+            const bool partial = kb == kb_partial;
+#pragma unroll
+            for (int j = 0; j < C::K_DMA; ++j)
+                if ((pieces >> j) & 1u)
+                    dma16_s(kt, partial ? k_voff_p[j] : k_voff[j], stage_off + (wave * C::K_DMA + j) * 1024);
+#pragma unroll
+            for (int j = 0; j < C::C_DMA; ++j)
+                if ((pieces >> (C::K_DMA + j)) & 1u)
+                    dma16_s(ct, partial ? c_voff_p[j] : c_voff[j], stage_off + C::KTILE + (wave * C::C_DMA + j) * 1024);
+            if (WEIGHTED && ((pieces >> (C::K_DMA + C::C_DMA)) & 1u)) {
+                // key weights of this (sense, tile): lane i fetches w[key0 + i] into the wave's own 256-B slot
+                const float *src = p.kw + batch * p.kw_bs + (int64_t)l * p.kw_ss + min(kb * C::BK + lane, S - 1);
+                dma4(src, stage_off + C::KTILE + C::CTILE + wave * 256);
+            }
+        };
+        constexpr uint32_t kAllPieces = (1u << C::DMA_PER_STAGE) - 1u;
+
+        f32x16 acc[C::NB];
+#pragma unroll
+        for (int n = 0; n < C::NB; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+
+        u32x4 qf[KD];
+#pragma unroll
+        for (int s = 0; s < KD; ++s) qf[s] = u32x4{0u, 0u, 0u, 0u};
+        float lse2 = 0.f;
+        // per-sense operands of this wave: my query's fragments (B operand of S^T = K Q^T) and its LSE
+        auto take_q = [&](int l) {
             const uint16_t *row = qg + (int64_t)my_q_clamped * p.qk_rs + (int64_t)l * p.qk_ss;
 #pragma unroll
             for (int s = 0; s < KD; ++s) {
@@ -271,96 +228,120 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
                 qf[s] = v;
             }
             lse2 = p.lse[((int64_t)batch * p.nsenses + l) * p.lse_stride + my_q_clamped] * kLog2e;
-        }
-    };
+        };
 
-    // ---- prologue: mailbox of step 0, then two tiles in flight ---------------------------------------
-    MixCursor cur = {0, 0, 0}, cur1 = cur, cur2;
-    if (C::SUPER && wave_has_rows) issue_q(0);
-    issue(0, cur);
-    advance(cur1);
-    cur2 = cur1;
-    if (nsteps > 1) issue(1, cur1);
-    advance(cur2);
+        // S^T of the 32-key half kk of the tile in ring slot byte offset `stage`
+        auto scores = [&](int stage, int kk) {
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KD; ++s) {
+                const u32x4 a = lds_read_16B(smem, k_read_off[s] + stage + kk * 32 * C::KROW);
+                st = E::mfma(a, qf[s], st);
+            }
+            return st;
+        };
+        auto exponentiate = [&](f32x16 &st) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = fast_exp2(fmaf(st[r], c2, -lse2));
+        };
+        auto pack = [&](const f32x16 &st, u32x4 (&pf)[2]) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pf[ks][i] = E::pack2(st[ks * 8 + 2 * i], st[ks * 8 + 2 * i + 1]);
+        };
+        // C^T operand of column block n at LDS byte offset `rows` (16 keys x 256 columns)
+        auto c_operand = [&](int rows, int n) {
+            const u32x2 lo = lds_read_tr16_8B(smem, c_read_off[n & 3] + (n >> 2) * 256 + rows);
+            const u32x2 hi = lds_read_tr16_8B(smem, c_read_off[n & 3] + (n >> 2) * 256 + rows + 8 * C::CROW);
+            return u32x4{lo[0], lo[1], hi[0], hi[1]};
+        };
+        // O^T += C^T P^T for 16 keys (ks) of half kk
+        auto pv = [&](int stage, int kk, int ks, const u32x4 &pfk) {
+            const int rows = stage + C::KTILE + (kk * 32 + ks * 16) * C::CROW;
+#pragma unroll
+            for (int n = 0; n < C::NB; ++n)
+                if (FULL || n < nb_live) acc[n] = E::mfma(c_operand(rows, n), pfk, acc[n]);
+        };
 
-    // One pipeline step.  SLOT: the ring slot as a compile-time constant (the loop below is unrolled by the ring
-    // depth so that the LDS addresses of the operand reads fold into instruction offsets).
-    auto ring_step = [&](int step, auto SLOT) {
-        constexpr int kSlot = decltype(SLOT)::value;
-        const int l = cur.l;
-        const int kb = cur.st * sup + cur.kk;
-        // my share of tile `step` (and my mailbox, which is older than tile step+1 in the queue) has
-        // landed; the tile after it may still be in flight ...
-#if !defined(BP_ABL_MIX_NOSYNC) && !defined(BP_ABL_MIX_NODMA)   // ablation builds: timing only, wrong results
-        if (step + 1 < nsteps) wait_vmcnt<C::DMA_PER_STAGE>(); else wait_vmcnt<0>();
-#endif
-#if !defined(BP_ABL_MIX_NOSYNC) && !defined(BP_ABL_MIX_NOBARRIER)
-        // ... and so has everybody else's; all waves are also done reading tile step-1
-        __builtin_amdgcn_s_barrier();
-#endif
-        if (cur.kk == 0 && wave_has_rows) take_q(l);
-        if (C::SUPER && step + 1 < nsteps && cur1.kk == 0 && wave_has_rows) {
-            // next step starts a new (super-tile, sense): refill the mailbox.  Queued BEFORE tile step+2, so
-            // the counted wait at the top of the next step covers it.
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of the old contents are done
-            issue_q(cur1.l);
-        }
-        // tile step+2 refills the slot that was read during step-1: pieces go out in slots 0..4 below
-#ifdef BP_MIX_BURST
-        for (int sl = 0; sl < N_SLOTS; ++sl) issue_slot(step + 2, cur2, sl);
-#else
-        issue_slot(step + 2, cur2, 0);
-#endif
+        // ---- steady-state step: every row sees every key of the tile; softmax of half 1 under the MFMAs of half 0.
+        // Pure arithmetic is not ordered by source position (nor by sched_barrier, which only freezes the order
+        // instruction selection happened to pick), and hipcc on its own issues all VALU first and the MFMAs back to
+        // back.  So the interleave is pinned with EMPTY volatile asm statements: each one "rewrites" a value, asm
+        // volatile statements keep their program order, hence whatever produces the value sits before its pin and
+        // whatever consumes the pinned value after it.
+        auto clean_step = [&](int stage, int l2, int kb2, int slot2) {
+            u32x4 pf0[2], pf1[2];
+            {
+                f32x16 st0 = scores(stage, 0);
+                exponentiate(st0);
+                pack(st0, pf0);
+            }
+            f32x16 st1 = scores(stage, 1);
+            issue(l2, kb2, slot2, 0x01u);
+            // 8 MFMAs of half 0, keys 0..15, each followed by 2 fma + 2 exp of half 1; the C operand of MFMA n+1 is
+            // requested before MFMA n issues, so the LDS latency hides behind a full MFMA
+            {
+                const int rows = stage + C::KTILE;
+                u32x4 a = c_operand(rows, 0);
+#pragma unroll
+                for (int n = 0; n < C::NB; ++n) {
+                    u32x4 a_next = a;
+                    if (n + 1 < C::NB) a_next = c_operand(rows, n + 1);
+                    asm volatile("" : "+v"(a));
+                    acc[n] = E::mfma(a, pf0[0], acc[n]);
+                    asm volatile("" : "+v"(acc[n]));
+                    float x0 = st1[2 * n], x1 = st1[2 * n + 1];
+                    asm volatile("" : "+v"(x0), "+v"(x1));
+                    x0 = fast_exp2(fmaf(x0, c2, -lse2));
+                    x1 = fast_exp2(fmaf(x1, c2, -lse2));
+                    asm volatile("" : "+v"(x0), "+v"(x1));
+                    st1[2 * n] = x0;
+                    st1[2 * n + 1] = x1;
+                    a = a_next;
+                }
+            }
+            issue(l2, kb2, slot2, 0x02u);
+            // 8 MFMAs of half 0, keys 16..31, each followed by one pack of half 1
+            {
+                const int rows = stage + C::KTILE + 16 * C::CROW;
+                u32x4 a = c_operand(rows, 0);
+#pragma unroll
+                for (int n = 0; n < C::NB; ++n) {
+                    u32x4 a_next = a;
+                    if (n + 1 < C::NB) a_next = c_operand(rows, n + 1);
+                    asm volatile("" : "+v"(a));
+                    acc[n] = E::mfma(a, pf0[1], acc[n]);
+                    asm volatile("" : "+v"(acc[n]));
+                    uint32_t w = E::pack2(st1[2 * n], st1[2 * n + 1]);
+                    asm volatile("" : "+v"(w));
+                    pf1[n >> 2][n & 3] = w;
+                    a = a_next;
+                }
+            }
+            issue(l2, kb2, slot2, 0x0cu);
+            pv(stage, 1, 0, pf1[0]);
+            issue(l2, kb2, slot2, kAllPieces & ~0x0fu);
+            pv(stage, 1, 1, pf1[1]);
+        };
 
-        {
-            const int stage_off = kSlot * C::STAGE;
+        // ---- a step that touches the diagonal region (or carries key weights): per-half liveness, masking
+        auto edge_step = [&](int stage, int l, int kb, int l2, int kb2, int slot2) {
+            issue(l2, kb2, slot2, 0x01u);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int sub = kb * 2 + kk;
                 const bool live = wave_has_rows && sub <= my_diag_sub;
-                const int coff = stage_off + C::KTILE + kk * 32 * C::CROW;
                 u32x4 pf[2];
-                auto pv = [&](int ks) {
-                    const int rows = coff + ks * 16 * C::CROW;
-#pragma unroll
-                    for (int n = 0; n < C::NB; ++n) {
-                        if (FULL || n < nb_live) {
-#ifdef BP_ABL_MIX_NOCREAD
-                            u32x4 a = qf[n % KD];
-                            asm volatile("" : "+v"(a));
-#else
-                            const u32x2 lo = lds_read_tr16_8B(smem, c_read_off[n] + rows);
-                            const u32x2 hi = lds_read_tr16_8B(smem, c_read_off[n] + rows + 8 * C::CROW);
-                            const u32x4 a = {lo[0], lo[1], hi[0], hi[1]};
-#endif
-                            acc[n] = E::mfma(a, pf[ks], acc[n]);
-                        }
-                    }
-                };
                 if (live) {
-                    // one 32-key sub-block: S^T (KD MFMAs) -> P^T -> O^T += C^T P^T (2*NB MFMAs)
-                    const int koff = stage_off + kk * 32 * C::KROW;
-                    f32x16 st;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) st[r] = 0.f;
-#ifndef BP_ABL_MIX_NOS
-#pragma unroll
-                    for (int s = 0; s < KD; ++s) {
-                        const u32x4 a = lds_read_16B(smem, k_read_off[s] + koff);
-                        st = E::mfma(a, qf[s], st);
-                    }
-#ifndef BP_ABL_MIX_NOEXP
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) st[r] = fast_exp2(fmaf(st[r], c2, -lse2));
-#endif
-#else
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) st[r] = lse2;
-#endif
+                    f32x16 st = scores(stage, kk);
+                    exponentiate(st);
                     if (WEIGHTED) {
                         // intervention hook: alpha[b, l, :, key] *= w[b, l, key]  (register r holds key
                         // (r & 3) + 8 (r >> 2) + 4 hh of the sub-block: four runs of four consecutive keys)
-                        const int wbase = stage_off + C::KTILE + C::CTILE + wave * 256 + (kk * 32 + 4 * hh) * 4;
+                        const int wbase = stage + C::KTILE + C::CTILE + wave * 256 + (kk * 32 + 4 * hh) * 4;
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const u32x4 w4 = lds_read_16B(smem, wbase + g * 32);
@@ -371,16 +352,11 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
                             }
                         }
                     }
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            pf[ks][i] = E::pack2(st[ks * 8 + 2 * i], st[ks * 8 + 2 * i + 1]);
+                    pack(st, pf);
                     if (sub == my_diag_sub) {
                         // Diagonal sub-block (its first key is q0): clear the 16-bit P entries whose key
-                        // lies above my query.  Done on the packed words with AND masks, in a small
-                        // wave-uniform branch, so the common path carries no mask arithmetic and the MFMA
-                        // code exists once.  (AND also kills an inf from an invisible, larger score.)
+                        // lies above my query, with AND masks on the packed words (AND also kills an inf
+                        // from an invisible, larger score).
 #pragma unroll
                         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -391,46 +367,119 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
                                 pf[ks][i] &= keep;
                             }
                     }
-                    pv(0);
+                    pv(stage, kk, 0, pf[0]);
                 }
-#ifndef BP_MIX_BURST
-                issue_slot(step + 2, cur2, 2 * kk + 1);
-#endif
-                if (live) pv(1);
-#ifndef BP_MIX_BURST
-                issue_slot(step + 2, cur2, 2 * kk + 2);
-#endif
+                issue(l2, kb2, slot2, kk == 0 ? 0x02u : (kAllPieces & ~0x0fu));
+                if (live) pv(stage, kk, 1, pf[1]);
+                if (kk == 0) issue(l2, kb2, slot2, 0x0cu);
+            }
+        };
+
+        // ---- pipeline: two tiles in flight ---------------------------------------------------------------
+        // step -> (sense, key tile); a step past the end re-fetches the last tile (harmless, keeps every wave's
+        // DMA count per step constant so the counted wait below never changes).  The clean and the edge steps
+        // of a sense run in two consecutive loops, each with ONE body: the accumulators then never meet at an
+        // if/else join (hipcc answers such a join of 128 registers with copies and spills).
+        int l2 = 0, kb2 = 0;                     // (sense, tile) of step + 2
+        auto advance2 = [&]() {
+            if (kb2 + 1 < nkb) { ++kb2; }
+            else if (l2 + 1 < p.nsenses) { ++l2; kb2 = 0; }
+        };
+        issue(0, 0, 0, kAllPieces);
+        advance2();
+        issue(l2, kb2, 1, kAllPieces);
+        advance2();
+
+        int slot = 0;                            // ring slot of the current step
+        auto step_begin = [&]() {
+            wait_vmcnt<C::DMA_PER_STAGE>();   // my share of the current tile has landed (the next may be in flight)
+            __builtin_amdgcn_s_barrier();     // ... and everybody's; all waves are done reading slot (slot + 2) % 3
+        };
+        auto step_end = [&]() {
+            slot = slot == 2 ? 0 : slot + 1;
+            advance2();
+        };
+        for (int l = 0; l < p.nsenses; ++l) {
+            if (wave_has_rows) take_q(l);
+            for (int kb = 0; kb < nkb_clean; ++kb) {
+                step_begin();
+                clean_step(slot * C::STAGE, l2, kb2, slot >= 1 ? slot - 1 : 2);
+                step_end();
+            }
+            for (int kb = nkb_clean; kb < nkb; ++kb) {
+                step_begin();
+                edge_step(slot * C::STAGE, l, kb, l2, kb2, slot >= 1 ? slot - 1 : 2);
+                step_end();
             }
         }
-        advance(cur); advance(cur1); advance(cur2);
-    };
-    static_assert(C::NSTAGE == 3, "the unrolled loop assumes a 3-slot ring");
-    for (int step = 0; step < nsteps; step += 3) {
-        ring_step(step, std::integral_constant<int, 0>{});
-        if (step + 1 < nsteps) ring_step(step + 1, std::integral_constant<int, 1>{});
-        if (step + 2 < nsteps) ring_step(step + 2, std::integral_constant<int, 2>{});
+        wait_vmcnt<0>();   // the two re-fetched tiles: nothing may still be landing when the next job refills the ring
+
+        if (wave_has_rows && my_q < S) {
+            uint16_t *og = reinterpret_cast<uint16_t *>(p.o) + batch * p.o_bs + (int64_t)my_q * p.o_rs;
+#pragma unroll
+            for (int n = 0; n < C::NB; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = col_base + n * 32 + 8 * g + 4 * hh;
+                    if (col < p.dout) {
+                        u32x2 w = {E::pack2(acc[n][4 * g + 0], acc[n][4 * g + 1]),
+                                   E::pack2(acc[n][4 * g + 2], acc[n][4 * g + 3])};
+                        *reinterpret_cast<u32x2 *>(og + col) = w;
+                    }
+                }
+        }
     }
 
-    if (!wave_has_rows || my_q >= S) return;
-    uint16_t *og = reinterpret_cast<uint16_t *>(p.o) + batch * p.o_bs + (int64_t)my_q * p.o_rs;
-#pragma unroll
-    for (int n = 0; n < C::NB; ++n)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int col = col_base + n * 32 + 8 * g + 4 * hh;
-            if (col < p.dout) {
-                u32x2 w = {E::pack2(acc[n][4 * g + 0], acc[n][4 * g + 1]),
-                           E::pack2(acc[n][4 * g + 2], acc[n][4 * g + 3])};
-                *reinterpret_cast<u32x2 *>(og + col) = w;
-            }
+    // the last workgroup to run out of work re-arms the queues for the next launch
+    if (tid == 0) {
+        const unsigned prev = atomicAdd(&queues->done, 1u);
+        if (prev == gridDim.x - 1) {
+            for (int q = 0; q < 8; ++q) atomicExch(&queues->ticket[q], 0u);
+            atomicExch(&queues->done, 0u);
         }
+    }
+}
+
+// Queue state for the persistent launch: a ring of 64-byte records in device memory owned by the library, one per
+// launch in flight (zero-initialised with the module; every launch leaves its record zeroed again).  Consecutive
+// launches take consecutive records, so two launches can only meet on one record if 64 of them are in flight
+// at once on different streams.
+constexpr int kMixQueueRing = 64;
+__device__ MixQueues g_mix_queues[kMixQueueRing];
+
+static MixQueues *next_queue_record() {
+    static std::atomic<unsigned> counter{0};
+    thread_local int cached_dev = -1;
+    thread_local MixQueues *base = nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (dev != cached_dev) {
+        void *ptr = nullptr;
+        if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_mix_queues)) != hipSuccess) return nullptr;
+        base = static_cast<MixQueues *>(ptr);
+        cached_dev = dev;
+    }
+    return base + (counter.fetch_add(1u, std::memory_order_relaxed) % kMixQueueRing);
+}
+
+static int mix_persistent_grid() {
+    thread_local int cached_dev = -1, cus = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev != cached_dev) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cached_dev = dev;
+    }
+    return cus;
 }
 
 template <class ET, int KD>
-static hipError_t launch_kd(const MixParams &p, hipStream_t stream) {
-    const int grid = p.order >= 2 ? ((p.b + 7) / 8) * 8 * p.n_chunks * p.n_qtiles
-                                  : xcd_grid(p.b * p.n_chunks, p.n_qtiles);
-    dim3 g(grid), t(512);
+static hipError_t launch_kd(MixParams p, hipStream_t stream) {
+    p.queues = next_queue_record();
+    if (p.queues == nullptr) return hipErrorInvalidDevice;
+    const int njobs = p.b * p.n_chunks * p.n_qtiles;
+    const int cus = mix_persistent_grid();
+    dim3 g(njobs < cus ? njobs : cus), t(512);   // 120 KB of LDS: one workgroup per CU
     if (p.kw != nullptr) {
         if (p.dout % 256 == 0) hipLaunchKernelGGL((sense_mix_dma_kernel<ET, KD, true, true>), g, t, 0, stream, p);
         else hipLaunchKernelGGL((sense_mix_dma_kernel<ET, KD, false, true>), g, t, 0, stream, p);
@@ -453,7 +502,7 @@ static hipError_t launch_et(const MixParams &p, hipStream_t stream) {
     }
 }
 
-// Requires: d_k % 8 == 0, d_out % 8 == 0, all bases 16-byte aligned, all strides multiples of 8.
+// Requires: d_k % 8 == 0, d_out % 8 == 0, all bases 16-byte aligned, all strides multiples of 8, n_qtiles <= 256.
 hipError_t launch_sense_mix_dma(const MixParams &p, int dtype, hipStream_t stream) {
     return dtype == 1 ? launch_et<BF16>(p, stream) : launch_et<F16>(p, stream);
 }

@@ -31,6 +31,7 @@ def fused_dense_gelu_dense_func(x, weight1, weight2, bias1=None, bias2=None, sav
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1])
     if (x2.is_cuda and bias1 is not None and x2.dtype in (torch.float16, torch.bfloat16)
+            and weight1.dtype == x2.dtype and bias1.dtype == x2.dtype       # not under AMP (fp32 parameters)
             and not torch.is_grad_enabled()):
         hidden = torch._addmm_activation(bias1, x2, weight1.t(), use_gelu=True)   # tanh GELU epilogue
     else:

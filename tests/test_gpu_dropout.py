@@ -35,7 +35,7 @@ def test_attention_dropout_mask_is_the_documented_function(shape, causal):
     """S_dmask sign bits == tests/philox_ref.py, bit for bit; magnitudes == the undropped probabilities."""
     bp = _bp()
     b, h, s, d = shape
-    p_drop, seed, offset = 0.17, 0x1234567890ABCDEF - 2 ** 64, 987654321
+    p_drop, seed, offset = 0.17, -0x1234567890ABCDEF, 987654321
     torch.manual_seed(0)
     qkv = torch.randn(b, s, 3, h, d, device=DEV, dtype=torch.bfloat16)
     q, k, v = qkv.unbind(2)
@@ -207,9 +207,9 @@ def test_dropout_layer_norm_training(hidden_size, input_dtype, residual_dtype, w
     assert (x0.grad - x0_ref.grad).abs().max() <= 4 * (x0_pt.grad - x0_ref.grad).abs().max() + 1e-4
     if has_residual:
         assert (x1.grad - x1_ref.grad).abs().max() <= 4 * (x1_pt.grad - x1_ref.grad).abs().max() + 1e-4
-    assert (model.weight.grad - model_ref.weight.grad).abs().max() <= \\
+    assert (model.weight.grad - model_ref.weight.grad).abs().max() <= \
         2 * (model_pt.weight.grad - model_ref.weight.grad).abs().max() + 3e-5
-    assert (model.bias.grad - model_ref.bias.grad).abs().max() <= \\
+    assert (model.bias.grad - model_ref.bias.grad).abs().max() <= \
         2 * (model_pt.bias.grad - model_ref.bias.grad).abs().max() + 3e-5
 
 
