@@ -33,6 +33,8 @@ SIGNATURES = {
     'bp_sense_alpha': (_i32, [_ptr] * 3 + [_i32] * 5 + [_i64] * 4 + [_f32, _i32, _ptr]),
     'bp_sense_mix': (_i32, [_ptr] * 4 + [_i32] * 6 + [_i64] * 9 + [_f32, _i32, _ptr]),
     'bp_sense_mix_weighted': (_i32, [_ptr] * 5 + [_i32] * 6 + [_i64] * 11 + [_f32, _i32, _ptr]),
+    'bp_sense_mix_dc': (_i32, [_ptr] * 4 + [_i32] * 5 + [_i64] * 9 + [_f32, _i32, _ptr]),
+    'bp_sense_dq_dk': (_i32, [_ptr] * 6 + [_i32] * 5 + [_i64] * 11 + [_f32, _i32, _ptr]),
     'bp_add_layer_norm': (_i32, [_ptr] * 6 + [_i64, _i32, _f32] + [_i32] * 4 + [_ptr]),
     'bp_dropout_add_layer_norm': (_i32, [_ptr] * 7 + [_i64, _i32, _f32] + [_i32] * 5 + [_f32, _ptr, _ptr]),
     'bp_dropout_add_layer_norm_bwd': (_i32, [_ptr] * 9 + [_i64, _i32, _f32] + [_i32] * 4 + [_f32, _ptr, _ptr]),
@@ -447,14 +449,71 @@ def softmax_bwd_causal_(alpha, dalpha, softmax_scale):
     return dalpha
 
 
+SLAB = 128   # queries per slab of the dq / dk backward (fixed by the kernels)
+
+
+def sense_mix_dc(qk, dout, lse, softmax_scale, like):
+    """dcontent (B,S,k,d_out) of sense_mix: bp_sense_mix_dc (alpha recomputed from the saved lse, never stored).
+    `like`: the forward's content tensor (shape / dtype / device of the result)."""
+    b, s, k, dk = _check_qk(qk)
+    dcontent = torch.empty((b, s, k, like.shape[-1]), dtype=like.dtype, device=like.device)
+    with torch.cuda.device(qk.device):
+        code = lib().bp_sense_mix_dc(
+            qk.data_ptr(), dout.data_ptr(), lse.data_ptr(), dcontent.data_ptr(), b, s, k, dk, like.shape[-1],
+            qk.stride(0), qk.stride(1), qk.stride(2), qk.stride(3), dout.stride(0), dout.stride(1),
+            dcontent.stride(0), dcontent.stride(1), dcontent.stride(2), float(softmax_scale), _dtype_code(qk),
+            _stream())
+    _check(code, 'bp_sense_mix_dc')
+    return dcontent
+
+
+def sense_dqk(qk, content, dout, lse, softmax_scale):
+    """dqk (like qk) of sense_mix.  The 768-deep product dP_l[t,s] = dout[t].C[s,l] is a plain GEMM and goes to the
+    BLAS library, slab by slab (128 queries), TRANSPOSED into a (B, S*k, 128) buffer that is reused: the content's
+    own storage (B, S*k, d) is its left operand as it stands, so nothing is copied or permuted.  bp_sense_dq_dk then
+    turns each slab into dq rows and dk contributions (softmax backward + the two thin products) on the fly."""
+    b, s, k, dk = _check_qk(qk)
+    d = content.shape[-1]
+    c_flat = content.reshape(b, s * k, d)                      # a view for the (B,S,k,d) storage layout
+    dqk = torch.empty_like(qk)
+    dk_acc = torch.zeros((b, s, k, dk), dtype=torch.float32, device=qk.device)
+    dsum = torch.empty((b, k, round_up(s, 16)), dtype=torch.float32, device=qk.device)
+    buf = torch.empty(b * s * k * SLAB, dtype=qk.dtype, device=qk.device)
+    code_dt, stream = _dtype_code(qk), _stream()
+    for t0 in range(0, s, SLAB):
+        n = min(s, t0 + SLAB) * k
+        rows = dout[:, t0:t0 + SLAB]
+        if rows.shape[1] < SLAB:                               # last, partial slab: pad the queries with zeros
+            rows = torch.nn.functional.pad(rows, (0, 0, 0, SLAB - rows.shape[1]))
+        dpt = buf[:b * n * SLAB].view(b, n, SLAB)
+        torch.bmm(c_flat[:, :n], rows.transpose(1, 2), out=dpt)
+        with torch.cuda.device(qk.device):
+            code = lib().bp_sense_dq_dk(
+                qk.data_ptr(), dpt.data_ptr(), lse.data_ptr(), dsum.data_ptr(), dqk.data_ptr(), dk_acc.data_ptr(),
+                b, s, k, dk, t0, qk.stride(0), qk.stride(1), qk.stride(2), qk.stride(3), dpt.stride(0),
+                dqk.stride(0), dqk.stride(1), dqk.stride(3), dk_acc.stride(0), dk_acc.stride(1), dk_acc.stride(2),
+                float(softmax_scale), code_dt, stream)
+        _check(code, 'bp_sense_dq_dk')
+    dqk[:, :, 1] = dk_acc
+    return dqk
+
+
+def _fused_mix_backward_ok(qk, content, key_weight):
+    return (key_weight is None and qk.shape[-1] % 8 == 0 and content.shape[-1] % 8 == 0 and qk.is_contiguous()
+            and content.stride(-1) == 1 and content.stride(2) == content.shape[-1]
+            and content.stride(1) == content.shape[2] * content.shape[-1]
+            and content.stride(0) == content.shape[1] * content.stride(1) and qk.shape[1] <= 65536)
+
+
 class SenseMixFn(torch.autograd.Function):
-    """Differentiable fused sense contraction.  Forward: LSE pre-pass + bp_sense_mix_weighted (alpha never
-    stored).  Backward (second half): alpha is rebuilt once by bp_sense_alpha from the
-    saved LSE, the two vocabulary-free big products run as batched GEMMs,
-        dC_l = (alpha_l * w_l)^T dout        dA_l = dout C_l^T (* w_l)
-    bp_softmax_bwd_causal turns dA into the score gradient in place, and two thin GEMMs give dq_l, dk_l.
-    Memory: two (B,k,S,S) 16-bit buffers during backward only; the reference's autograd keeps three in fp32
-    alive from the forward on."""
+    """Differentiable fused sense contraction.  Forward: LSE pre-pass + bp_sense_mix_weighted (alpha never stored).
+    Backward (second half), alpha recomputed from the saved LSE inside the kernels:
+        dC_l = alpha_l^T dout                                   bp_sense_mix_dc   (the forward kernel, roles swapped)
+        dP_l = dout C_l^T   (slabs of 128 queries, BLAS)  ->  dS = alpha (dP - rowsum(alpha dP))
+        dq_l = scale dS k_l,  dk_l = scale dS^T q_l             bp_sense_dq_dk
+    Peak extra memory: one (B, S*k, 128) 16-bit slab; the reference's autograd keeps three (B,k,S,S) fp32 tensors
+    alive from the forward on.  With an intervention `key_weight` (inference-time experiments) or shapes the fused
+    kernels do not take, the older alpha-rebuilding formulation below runs instead."""
 
     @staticmethod
     def forward(ctx, qk, content, softmax_scale, key_weight):
@@ -468,8 +527,19 @@ class SenseMixFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         qk, content, lse, key_weight = ctx.saved_tensors
-        b, s, _, k, dk = qk.shape
         dout = dout.contiguous()
+        if not _fused_mix_backward_ok(qk, content, key_weight):
+            return _sense_mix_backward_rebuild(ctx, qk, content, lse, key_weight, dout)
+        dcontent = sense_mix_dc(qk, dout, lse, ctx.scale, content) if ctx.needs_input_grad[1] else None
+        dqk = sense_dqk(qk, content, dout, lse, ctx.scale) if ctx.needs_input_grad[0] else None
+        return dqk, dcontent, None, None
+
+
+def _sense_mix_backward_rebuild(ctx, qk, content, lse, key_weight, dout):
+    """alpha rebuilt once by bp_sense_alpha from the saved LSE (two (B,k,S,S) 16-bit buffers), batched GEMMs,
+    bp_softmax_bwd_causal in place, two thin GEMMs: the round-1 formulation, kept for key_weight / odd shapes."""
+    if True:
+        b, s, _, k, dk = qk.shape
         alpha = sense_alpha(qk, ctx.scale, lse=lse)                               # (B,k,S,S)
         weighted = alpha if key_weight is None else alpha * key_weight.unsqueeze(2).to(alpha.dtype)
         g = dout.unsqueeze(1)                                                      # (B,1,S,d)

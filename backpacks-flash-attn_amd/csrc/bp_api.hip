@@ -308,6 +308,69 @@ int bp_sense_mix_weighted(const void *qk, const void *content, const float *key_
     return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
 }
 
+int bp_sense_mix_dc(const void *qk, const void *dout, const float *lse, void *dcontent,
+                    int batch, int seqlen, int nsenses, int d_k, int d_out,
+                    int64_t qk_batch_stride, int64_t qk_row_stride, int64_t qk_two_stride, int64_t qk_sense_stride,
+                    int64_t do_batch_stride, int64_t do_row_stride,
+                    int64_t c_batch_stride, int64_t c_row_stride, int64_t c_sense_stride,
+                    float softmax_scale, int dtype, bp_stream_t stream) {
+    if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
+    if (d_k < 8 || d_k > 128 || d_k % 8 != 0) return BP_ERR_HEAD_DIM;
+    if (d_out < 8 || d_out % 8 != 0) return BP_ERR_DOUT;
+    if (batch <= 0 || nsenses <= 0 || seqlen <= 0 || seqlen > 65536) return BP_ERR_SHAPE;
+    if (qk == nullptr || dout == nullptr || lse == nullptr || dcontent == nullptr) return BP_ERR_SHAPE;
+    if (!scale_ok(softmax_scale)) return BP_ERR_SCALE;
+    const uint16_t *qp = static_cast<const uint16_t *>(qk);
+    if (!aligned16(qp) || !aligned16(qp + qk_two_stride) || !aligned16(dout) || !aligned16(dcontent)) return BP_ERR_SHAPE;
+    const int64_t strides[] = {qk_batch_stride, qk_row_stride, qk_sense_stride, do_batch_stride, do_row_stride,
+                               c_batch_stride, c_row_stride, c_sense_stride};
+    for (int64_t st : strides) if (!mult8(st)) return BP_ERR_SHAPE;
+    bp::MixBwdParams p{};
+    p.q = qp; p.k = qp + qk_two_stride; p.dout = dout; p.dc = dcontent; p.lse = lse;
+    p.qk_bs = qk_batch_stride; p.qk_rs = qk_row_stride; p.qk_ss = qk_sense_stride;
+    p.do_bs = do_batch_stride; p.do_rs = do_row_stride;
+    p.c_bs = c_batch_stride; p.c_rs = c_row_stride; p.c_ss = c_sense_stride;
+    p.lse_stride = round_up(seqlen, 16);
+    p.b = batch; p.s = seqlen; p.nsenses = nsenses; p.dk = d_k; p.dout_cols = d_out;
+    p.n_ktiles = (seqlen + 255) / 256;
+    p.n_chunks = (d_out + 255) / 256;
+    p.scale_log2e = softmax_scale * bp::kLog2e;
+    hipError_t e = bp::launch_sense_mix_dc(p, dtype, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
+}
+
+int bp_sense_dq_dk(const void *qk, const void *dpt, const float *lse, float *dsum_ws, void *dqk, float *dk_acc,
+                   int batch, int seqlen, int nsenses, int d_k, int t0,
+                   int64_t qk_batch_stride, int64_t qk_row_stride, int64_t qk_two_stride, int64_t qk_sense_stride,
+                   int64_t dpt_batch_stride,
+                   int64_t dqk_batch_stride, int64_t dqk_row_stride, int64_t dqk_sense_stride,
+                   int64_t dka_batch_stride, int64_t dka_row_stride, int64_t dka_sense_stride,
+                   float softmax_scale, int dtype, bp_stream_t stream) {
+    if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
+    if (d_k < 8 || d_k > 128 || d_k % 8 != 0) return BP_ERR_HEAD_DIM;
+    if (batch <= 0 || nsenses <= 0 || seqlen <= 0 || t0 < 0 || t0 >= seqlen || t0 % 128 != 0) return BP_ERR_SHAPE;
+    if (!qk || !dpt || !lse || !dsum_ws || !dqk || !dk_acc) return BP_ERR_SHAPE;
+    if (!scale_ok(softmax_scale)) return BP_ERR_SCALE;
+    const uint16_t *qp = static_cast<const uint16_t *>(qk);
+    if (!aligned16(qp) || !aligned16(qp + qk_two_stride) || !aligned16(dpt) || !aligned16(dqk) || !aligned16(dk_acc))
+        return BP_ERR_SHAPE;
+    const int64_t strides[] = {qk_batch_stride, qk_row_stride, qk_sense_stride, dpt_batch_stride, dqk_batch_stride,
+                               dqk_row_stride, dqk_sense_stride};
+    for (int64_t st : strides) if (!mult8(st)) return BP_ERR_SHAPE;
+    if ((dka_batch_stride | dka_row_stride | dka_sense_stride) & 3) return BP_ERR_SHAPE;
+    bp::SenseGradParams p{};
+    p.q = qp; p.k = qp + qk_two_stride; p.dpt = dpt; p.lse = lse; p.dsum = dsum_ws; p.dq = dqk; p.dk_acc = dk_acc;
+    p.qk_bs = qk_batch_stride; p.qk_rs = qk_row_stride; p.qk_ss = qk_sense_stride;
+    p.dpt_bs = dpt_batch_stride;
+    p.dq_bs = dqk_batch_stride; p.dq_rs = dqk_row_stride; p.dq_ss = dqk_sense_stride;
+    p.dka_bs = dka_batch_stride; p.dka_rs = dka_row_stride; p.dka_ss = dka_sense_stride;
+    p.lse_stride = round_up(seqlen, 16);
+    p.b = batch; p.s = seqlen; p.nsenses = nsenses; p.dk = d_k; p.t0 = t0;
+    p.scale = softmax_scale;
+    hipError_t e = bp::launch_sense_dq_dk(p, dtype, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
+}
+
 int bp_flash_bwd(const void *dout, const void *q, const void *k, const void *v, const void *out,
                  const float *softmax_lse, float *dsum_ws, void *dq, void *dk, void *dv,
                  const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k,

@@ -86,6 +86,42 @@ struct MixParams {
     MixQueues *queues;        // filled in by launch_sense_mix_dma
 };
 
+// backward of the sense combination (sense_mix_bwd.hip)
+struct MixBwdParams {
+    const void *q, *k;        // as MixParams
+    const void *dout;         // dout[b, t, :] = dout + b*do_bs + t*do_rs
+    void *dc;                 // dC[b, s, l, :] = dc + b*c_bs + s*c_rs + l*c_ss
+    const float *lse;         // (b, k, lse_stride)
+    int64_t qk_bs, qk_rs, qk_ss;
+    int64_t do_bs, do_rs;
+    int64_t c_bs, c_rs, c_ss;
+    int64_t lse_stride;
+    int b, s, nsenses, dk, dout_cols;
+    int n_ktiles;             // ceil(s / 256)
+    int n_chunks;             // ceil(dout_cols / 256)
+    float scale_log2e;
+    MixQueues *queues;        // filled in by launch_sense_mix_dc
+};
+hipError_t launch_sense_mix_dc(const MixBwdParams &p, int dtype, hipStream_t stream);
+
+struct SenseGradParams {
+    const void *q, *k;        // as MixParams
+    const void *dpt;          // (b, N, 128) 16-bit: dP^T slab, row s*k + l, column = query t0 + j
+    const float *lse;         // (b, k, lse_stride)
+    float *dsum;              // (b, k, lse_stride): D, written by the dq kernel, read by the dk kernel
+    void *dq;                 // dq_l[t] = dq + b*dq_bs + t*dq_rs + l*dq_ss   (16-bit)
+    float *dk_acc;            // dk_l[s] += at dk_acc + b*dka_bs + s*dka_rs + l*dka_ss   (fp32)
+    int64_t qk_bs, qk_rs, qk_ss;
+    int64_t dpt_bs;
+    int64_t dq_bs, dq_rs, dq_ss;
+    int64_t dka_bs, dka_rs, dka_ss;
+    int64_t lse_stride;
+    int b, s, nsenses, dk;
+    int t0;                   // first query of the slab (multiple of 128)
+    float scale;
+};
+hipError_t launch_sense_dq_dk(const SenseGradParams &p, int dtype, hipStream_t stream);
+
 struct SoftmaxBwdParams {
     const void *alpha;   // (n, s, s) 16-bit causal softmax output (zeros above the diagonal)
     void *dp;            // (n, s, s) 16-bit: gradient w.r.t. alpha in, gradient w.r.t. the scores out

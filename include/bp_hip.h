@@ -199,6 +199,46 @@ int bp_sense_mix_weighted(const void *qk, const void *content, const float *key_
                           float softmax_scale, int dtype, bp_stream_t stream);
 
 /*
+ * bp_sense_mix_dc -- backward of bp_sense_mix with respect to the content:
+ *   dcontent[b,s,l,:] = sum_{t>=s} alpha[b,l,t,s] * dout[b,t,:]
+ * alpha is recomputed from qk and the saved log-sum-exp; no (batch, nsenses, seqlen, seqlen) tensor exists.  The
+ * reference leaves this product to autograd through `torch.sum(contextualization @ content, dim=1)`
+ * (training/src/models/backpack.py:313).
+ *   qk        as in bp_sense_alpha, d_k % 8 == 0 (pad the projection, see ContextSelfAttn.project)
+ *   dout      (batch, seqlen, d_out) 16-bit, strides do_batch/do_row, last stride 1, d_out % 8 == 0
+ *   lse       (batch, nsenses, roundup(seqlen,16)) fp32: bp_sense_lse's result for this qk
+ *   dcontent  (batch, seqlen, nsenses, d_out) 16-bit, strides c_batch/c_row/c_sense (the content's own layout)
+ */
+int bp_sense_mix_dc(const void *qk, const void *dout, const float *lse, void *dcontent,
+                    int batch, int seqlen, int nsenses, int d_k, int d_out,
+                    int64_t qk_batch_stride, int64_t qk_row_stride, int64_t qk_two_stride, int64_t qk_sense_stride,
+                    int64_t do_batch_stride, int64_t do_row_stride,
+                    int64_t c_batch_stride, int64_t c_row_stride, int64_t c_sense_stride,
+                    float softmax_scale, int dtype, bp_stream_t stream);
+
+/*
+ * bp_sense_dq_dk -- backward of the sense weights with respect to qk, for ONE slab of 128 queries [t0, t0 + 128):
+ *   D_l[t]  = sum_s alpha_l[t,s] dP_l[t,s]        dS_l[t,s] = alpha_l[t,s] (dP_l[t,s] - D_l[t])
+ *   dq_l[t] = scale sum_s dS_l[t,s] k_l[s]   -> written to dqk[b, t, 0, l, :]   (rows of the slab)
+ *   dk_l[s] += scale sum_{t in slab} dS_l[t,s] q_l[t]   -> ADDED to dk_acc[b, s, l, :] (fp32; zero it before the
+ *              first slab, run the slabs one after the other on one stream: the sum is then deterministic)
+ * where dP_l[t,s] = dout[b,t,:] . content[b,s,l,:] comes precomputed, TRANSPOSED, from the caller:
+ *   dpt  (batch, N, 128) 16-bit, row index s * nsenses + l, column = query t0 + j, N = min(seqlen, t0 + 128) *
+ *        nsenses: the plain GEMM  content.view(batch, seqlen*nsenses, d)[:, :N] @ dout[:, t0:t0+128].T  (columns of
+ *        queries past the sequence: anything finite).  A (B, S*k, 128) buffer, 1/(S/128) of the alpha-sized ones.
+ *   dsum_ws  (batch, nsenses, roundup(seqlen,16)) fp32 scratch (D of the slab's rows is put there)
+ *   dqk      16-bit, laid out like qk (strides dqk_batch/dqk_row/dqk_sense, the q half at offset 0)
+ * Replaces what autograd does for ContextSelfAttn.forward (training/src/models/backpack.py:116-122).
+ */
+int bp_sense_dq_dk(const void *qk, const void *dpt, const float *lse, float *dsum_ws, void *dqk, float *dk_acc,
+                   int batch, int seqlen, int nsenses, int d_k, int t0,
+                   int64_t qk_batch_stride, int64_t qk_row_stride, int64_t qk_two_stride, int64_t qk_sense_stride,
+                   int64_t dpt_batch_stride,
+                   int64_t dqk_batch_stride, int64_t dqk_row_stride, int64_t dqk_sense_stride,
+                   int64_t dka_batch_stride, int64_t dka_row_stride, int64_t dka_sense_stride,
+                   float softmax_scale, int dtype, bp_stream_t stream);
+
+/*
  * bp_flash_bwd -- attention backward: dq, dk, dv from q, k, v, dout and the forward's out and softmax_lse.
  * Replaces flash_attn_cuda.bwd / mha_bwd (csrc/flash_attn/fmha_api.cpp:337-504) called by
  * _flash_attn_backward (flash_attn/flash_attn_interface.py:31-47), no-dropout path.  P is recomputed

@@ -4,8 +4,11 @@ forward metric); this script records what the training path costs on the HIP ker
 
     python scripts/bench_train_step.py [--batch 16] [--steps 5] [--model small]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 scripts/bench_train_step.py
-Weights fp32 master copies are not kept (the reference trains with bf16 autocast over fp32 weights; here the
-model is bf16 and AdamW runs on bf16 parameters -- a throughput probe, not a recipe)."""
+Default = the reference's recipe: fp32 parameters under 16-bit autocast (trainer precision 16,
+training/configs/trainer/default.yaml + experiment/owt/base.yaml), so DDP all-reduces 170.48 M fp32 gradients
+(682 MB), and GPT2Config's default dropout 0.1 (attention, residual, embedding) running inside the HIP kernels.
+`--pure-bf16` keeps bf16 parameters instead (half the all-reduce volume; a throughput probe, not the recipe),
+`--dropout 0` switches dropout off."""
 import argparse
 import json
 import os
@@ -25,6 +28,8 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--model', default='small')
+    ap.add_argument('--dropout', type=float, default=0.1)
+    ap.add_argument('--pure-bf16', action='store_true')
     a = ap.parse_args()
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
@@ -38,10 +43,10 @@ def main():
     from src.models.backpack import BackpackConfig, BackpackLMHeadModel
     cfg = BackpackConfig(vocab_size=50257, n_positions=a.seq, scale_attn_by_inverse_layer_idx=True,
                          use_flash_attn=True, fused_bias_fc=True, fused_dense_gelu_dense=True,
-                         fused_dropout_add_ln=True, pad_vocab_size_multiple=8, resid_pdrop=0.0, embd_pdrop=0.0,
-                         attn_pdrop=0.0, **MODELS[a.model])
+                         fused_dropout_add_ln=True, pad_vocab_size_multiple=8, resid_pdrop=a.dropout,
+                         embd_pdrop=a.dropout, attn_pdrop=a.dropout, **MODELS[a.model])
     torch.manual_seed(0)
-    model = BackpackLMHeadModel(cfg, device=dev, dtype=torch.bfloat16).train()
+    model = BackpackLMHeadModel(cfg, device=dev, dtype=torch.bfloat16 if a.pure_bf16 else torch.float32).train()
     net = model
     if world > 1:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True,
@@ -53,7 +58,8 @@ def main():
 
     def step():
         opt.zero_grad(set_to_none=True)
-        logits = net(ids).logits
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=not a.pure_bf16):
+            logits = net(ids).logits
         loss = loss_fn(logits.view(-1, logits.shape[-1]), labels.view(-1))
         loss.backward()
         opt.step()
@@ -75,7 +81,9 @@ def main():
         print(json.dumps({'metric': f'tokens/sec train step (fwd+loss+bwd+AdamW), Backpack-{a.model} seq={a.seq}',
                           'value': round(world * a.batch * a.seq * a.steps / dt, 1), 'unit': 'tokens/s',
                           'n_gpus': world, 'ms_per_step': round(dt / a.steps * 1e3, 2), 'batch_per_gpu': a.batch,
-                          'dtype': 'bf16', 'loss': round(float(loss.detach()), 4),
+                          'dtype': 'bf16' if a.pure_bf16 else 'bf16 autocast over fp32 parameters', 'dropout': a.dropout,
+                          'grad_allreduce_bytes': sum(p.numel() * p.element_size() for p in model.parameters()),
+                          'loss': round(float(loss.detach()), 4),
                           'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}))
 
 
