@@ -2,7 +2,7 @@
 at seq 1024, bf16, on N MI355X (BASELINE.json `metric`), plus the roofline fraction of the
 dominant HIP kernel and the CPU-eager baseline timed in the same run.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workload NAME]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B|auto] [--workload NAME]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -124,6 +124,35 @@ def algorithmic_work(cfg, batch, seq):
     }
 
 
+def pick_batch(model, make_ids, candidates, seq, device, steps=3):
+    """Untimed-region batch sweep: tokens/s of `steps` forwards at each candidate batch (after 2 warm-up
+    forwards); candidates that do not fit in HBM are skipped.  Returns (best batch, the sweep table)."""
+    table = []
+    for b in candidates:
+        try:
+            ids = make_ids(b)
+            with torch.no_grad():
+                for _ in range(2):
+                    model(ids).logits
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    model(ids).logits
+                torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            table.append(dict(batch=b, ms_per_step=round(dt * 1e3, 3), tokens_per_s=round(b * seq / dt, 1),
+                              peak_mem_gb=round(torch.cuda.max_memory_allocated(device) / 2**30, 1)))
+        except torch.OutOfMemoryError:
+            table.append(dict(batch=b, ms_per_step=None, tokens_per_s=0.0, peak_mem_gb=None, note='out of HBM'))
+        finally:
+            ids = None
+            torch.cuda.empty_cache()
+    best = max(table, key=lambda r: r['tokens_per_s'])
+    if not best['tokens_per_s']:
+        raise SystemExit('no candidate batch fits in HBM')
+    return best['batch'], table
+
+
 def cpu_baseline(model_name, seq, budget_s=15.0, threads=None):
     """The reference's eager CPU path (restated in oracle/ref_cpu.py, validated against the real
     reference by tests/golden/make_golden.py) on this host's cores, fp32.
@@ -175,7 +204,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=None, help='samples per GPU per step')
+    ap.add_argument('--batch', default='auto',
+                    help="samples per GPU per step, or 'auto' (default): time a few steps at each of "
+                         "--batch-candidates and keep the fastest (north_star: batch sized for 288 GB of HBM)")
+    ap.add_argument('--batch-candidates', default=None,
+                    help='comma-separated batch sizes tried by --batch auto (default: per workload)')
     ap.add_argument('--workload', default='small-1024', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-threads', type=int, default=None)
@@ -203,10 +236,24 @@ def main():
 
     model_name, seq, dtype_name, default_batch = WORKLOADS[args.workload]
     dtype = torch.bfloat16 if dtype_name == 'bf16' else torch.float16
-    batch = args.batch or default_batch
     cfg, model = build_model(model_name, seq, dtype, device)
-    ids = torch.randint(0, 50257, (batch, seq), device=device,
-                        generator=torch.Generator(device=device).manual_seed(1234 + rank))
+
+    def make_ids(b):
+        return torch.randint(0, 50257, (b, seq), device=device,
+                             generator=torch.Generator(device=device).manual_seed(1234 + rank))
+
+    sweep = None
+    if args.batch == 'auto':
+        cands = ([int(c) for c in args.batch_candidates.split(',')] if args.batch_candidates
+                 else [default_batch * m for m in (1, 2, 4, 8)])
+        batch, sweep = pick_batch(model, make_ids, cands, seq, device)
+        if dist is not None:    # every rank runs the batch rank 0 picked
+            t = torch.tensor([batch], device=device)
+            dist.broadcast(t, 0)
+            batch = int(t.item())
+    else:
+        batch = int(args.batch)
+    ids = make_ids(batch)
 
     clock = KernelClock()
     if not args.no_kernel_events and not args.graph:
@@ -293,6 +340,7 @@ def main():
                                    f'{cfg.n_head} heads, {cfg.n_layer} layers, k={cfg.num_content_vectors} '
                                    f'senses, vocab {cfg.vocab_size}, seq {seq}',
                        'batch_per_gpu': batch, 'global_batch': batch * world, 'seq_len': seq,
+                       'batch_choice': 'auto: fastest of the sweep in batch_sweep' if sweep else 'given',
                        'parallelism': f'{world} independent batch replicas (no data-path collective)'},
         }
         if kernel_rows:
@@ -301,24 +349,33 @@ def main():
             # HBM-bound fused add+LayerNorm, is listed in `kernels`.
             hot = [r for r in kernel_rows if r['kernel'] != 'add_layer_norm_kernel'] or kernel_rows
             dom = hot[0]
-            traffic = None
+            # HBM bytes per launch are NOT measured in this run (PMC counters need their own rocprofv3 pass):
+            # the figure is quoted from profiles/traffic.json, which names the tracked PMC summary it was
+            # computed from; null when no pass exists for this workload / batch.
+            traffic, traffic_source = None, None
             tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get(f"{args.workload}/b{batch}/{dom['kernel']}")
+                    tj = json.load(open(tpath))
+                    traffic = tj.get(f"{args.workload}/b{batch}/{dom['kernel']}")
+                    if traffic is not None:
+                        traffic_source = 'quoted from profiles/traffic.json: ' + tj.get('_source', 'rocprofv3 --pmc pass')
                 except Exception:
                     traffic = None
             if dom['kernel'] == 'add_layer_norm_kernel':
                 line['roofline'] = {'kernel': dom['kernel'], 'bound': 'hbm', 'achieved': dom['gbps'],
                                     'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': dom['hbm_frac'],
-                                    'traffic': traffic, 'avg_launch_ms': dom['avg_ms']}
+                                    'traffic': traffic, 'traffic_source': traffic_source,
+                                    'avg_launch_ms': dom['avg_ms']}
             else:
                 line['roofline'] = {'kernel': dom['kernel'], 'bound': 'mfma',
                                     'achieved': dom['tflops'], 'peak': PEAK_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                     'frac': dom['mfma_frac'], 'traffic': traffic,
-                                    'avg_launch_ms': dom['avg_ms'], 'hbm_gbps': dom['gbps'],
+                                    'traffic_source': traffic_source, 'avg_launch_ms': dom['avg_ms'], 'hbm_gbps': dom['gbps'],
                                     'hbm_frac': dom['hbm_frac']}
             line['kernels'] = kernel_rows
+        if sweep:
+            line['batch_sweep'] = sweep
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(model_name, seq, threads=args.cpu_threads)
         print(json.dumps(line), flush=True)

@@ -1,7 +1,7 @@
 """Micro-benchmark of the individual HIP kernels on synthetic N(0,1) data (never zeros: zero-filled
 inputs clock higher and flatter -- cdna_hip_programming.md section 5.4 rule 25).
 
-    python scripts/bench_kernels.py [--which flash,mix,lse,alpha] [--batch 64] [--seq 1024] [--iters 20]
+    python scripts/bench_kernels.py [--which flash,bwd,mix,lse,alpha,mixbwd,lnbwd,xent] [--batch 64] [--seq 1024] [--iters 20]
 Prints one JSON line per kernel with avg ms, algorithmic TFLOP/s and GB/s (SURVEY section 8d figures)."""
 import argparse
 import json
@@ -70,7 +70,7 @@ def main():
         # 5 matmuls of the textbook backward (S, dP, dV, dK, dQ); this split recomputes S and dP once more
         fl, by = 10 * (pairs if causal else S * S) * D * H * B, 16 * S * D * H * B
         res.append(dict(kernel='flash_bwd(dkdv+dq+dsum)', ms=ms, tflops=fl / ms / 1e9, gbps=by / ms / 1e6))
-    if 'lse' in which or 'mix' in which or 'alpha' in which:
+    if {'lse', 'mix', 'alpha', 'mixbwd'} & set(which):
         qk = torch.randn(B, S, 2, K, d // K, device=dev).to(dt)
     if 'lse' in which:
         ms = timeit(lambda: bp_hip.sense_lse(qk), a.iters)
@@ -84,12 +84,26 @@ def main():
         res.append(dict(kernel='sense_mix', ms=ms, tflops=2 * pairs * d * (1 + K) * B / ms / 1e9,
                         gbps=(4 + 2 * K + 2) * S * d * B / ms / 1e6))
     if 'alpha' in which:
-        Ba = min(B, 8)
+        Ba = min(B, 64)     # (Ba, k, S, S) 16-bit: 2.1 GB at 64 x 16 x 1024^2 -- far past the 256 MiB Infinity Cache
         lse = bp_hip.sense_lse(qk[:Ba])
         ms = timeit(lambda: bp_hip.sense_alpha(qk[:Ba], lse=lse), a.iters)
         by = (4 * S * d + 2 * K * S * S) * Ba
         res.append(dict(kernel='attn_probs(alpha)', batch=Ba, ms=ms, tflops=2 * pairs * d * Ba / ms / 1e9,
                         gbps=by / ms / 1e6))
+    if 'mixbwd' in which:
+        c = torch.randn(B, S, K, d, device=dev).to(dt)
+        dout = torch.randn(B, S, d, device=dev).to(dt)
+        lse = bp_hip.sense_lse(qk)
+        scale = (d // K) ** -0.5
+        ms = timeit(lambda: bp_hip.sense_mix_dc(qk, dout, lse, scale, c), a.iters)
+        # dC[j] = sum_i alpha[i,j] dout[i]: QK^T once per sense + alpha^T.dout per sense (a d-wide output per sense)
+        res.append(dict(kernel='sense_mix_dc', ms=ms, tflops=2 * pairs * d * (1 + K) * B / ms / 1e9,
+                        gbps=(4 + 2 + 2 * K) * S * d * B / ms / 1e6))
+        ms = timeit(lambda: bp_hip.sense_dqk(qk, c, dout, lse, scale), a.iters)
+        # dP = dout C^T (k d-wide dots per pair), then QK^T recomputed twice (dq and dk passes) + dS.K + dS^T.Q
+        res.append(dict(kernel='sense_dqk(slab gemm + dq + dk)', ms=ms,
+                        tflops=(2 * pairs * d * K + 8 * pairs * d) * B / ms / 1e9,
+                        gbps=(4 + 2 + 2 * K + 4) * S * d * B / ms / 1e6))
     if 'lnbwd' in which:
         rows, cols = B * S, d
         x = torch.randn(rows, cols, device=dev)

@@ -91,6 +91,32 @@ def test_argument_validation_returns_before_any_launch():
     assert h.bp_attn_probs_dropout(p, p, p, p, 1, 1, 64, 16, 16, 1, 1, 1, 1, 1, 1, 16, 1, 1, 1, 0.125, 1, 1,
                                    2.0, p, null) == -7
 
+    # fused sense-mix backward: d_k not a multiple of 8, d_out not a multiple of 8, null dcontent, odd stride, bad scale
+    mix_st = (64,) * 9
+    assert h.bp_sense_mix_dc(p, p, p, p, 1, 16, 4, 10, 64, *mix_st, 0.25, 1, null) == -2
+    assert h.bp_sense_mix_dc(p, p, p, p, 1, 16, 4, 16, 20, *mix_st, 0.25, 1, null) == -6
+    assert h.bp_sense_mix_dc(p, p, p, null, 1, 16, 4, 16, 64, *mix_st, 0.25, 1, null) == -3
+    assert h.bp_sense_mix_dc(p, p, p, p, 1, 16, 4, 16, 64, 64, 63, 64, 64, 64, 64, 64, 64, 64, 0.25, 1, null) == -3
+    assert h.bp_sense_mix_dc(p, p, p, p, 1, 16, 4, 16, 64, *mix_st, 0.0, 1, null) == -4
+    assert h.bp_sense_mix_dc(p, p, p, p, 1, 16, 4, 16, 64, *mix_st, 0.25, 9, null) == -1
+    # dq/dk slab kernel: slab start not a multiple of 128 / past the end, null workspace, fp32 stride not 16-byte
+    dq_st = (64,) * 11
+    assert h.bp_sense_dq_dk(p, p, p, p, p, p, 1, 256, 4, 16, 64, *dq_st, 0.25, 1, null) == -3
+    assert h.bp_sense_dq_dk(p, p, p, p, p, p, 1, 256, 4, 16, 256, *dq_st, 0.25, 1, null) == -3
+    assert h.bp_sense_dq_dk(p, p, p, null, p, p, 1, 256, 4, 16, 128, *dq_st, 0.25, 1, null) == -3
+    assert h.bp_sense_dq_dk(p, p, p, p, p, p, 1, 256, 4, 16, 128, *dq_st[:8], 64, 62, 64, 0.25, 1, null) == -3
+    assert h.bp_sense_dq_dk(p, p, p, p, p, p, 1, 256, 4, 12, 128, *dq_st, 0.25, 1, null) == -2
+    # fused (dropout +) add + LayerNorm: dropout without a generator state, fp32 x0 with a 16-bit residual stream,
+    # columns not a multiple of 4, misaligned dmask
+    assert h.bp_dropout_add_layer_norm(p, p, p, p, p, p, null, 8, 64, 1e-5, 1, 0, 1, 1, 1, 0.1, null, null) == -7
+    assert h.bp_dropout_add_layer_norm(p, p, p, p, p, p, null, 8, 64, 1e-5, 1, 1, 0, 0, 1, 0.0, null, null) == -1
+    assert h.bp_dropout_add_layer_norm(p, p, p, p, p, p, null, 8, 66, 1e-5, 1, 0, 1, 1, 1, 0.0, null, null) == -3
+    assert h.bp_dropout_add_layer_norm(p, p, p, p, p, p, ctypes.c_void_p(0x1002), 8, 64, 1e-5, 1, 0, 1, 1, 1, 0.1, p,
+                                       null) == -3
+    assert h.bp_dropout_add_layer_norm_bwd(p, p, p, p, p, p, p, p, p, 8, 64, 1e-5, 1, 0, 1, 1, 1.5, p, null) == -7
+    assert h.bp_dropout_add_layer_norm_bwd(p, p, p, p, p, p, p, p, p, 8, 64, 1e-5, 1, 1, 0, 1, 0.0, null, null) == -1
+    assert h.bp_dropout_add_layer_norm_bwd(p, p, p, p, p, p, p, p, null, 8, 64, 1e-5, 1, 0, 1, 1, 0.0, null, null) == -3
+
 
 def test_philox_restatement_known_answers():
     """tests/philox_ref.py (the host restatement of csrc/bp_philox.h) against the published Philox2x32-10

@@ -265,7 +265,8 @@ def test_bench_script_contract():
                 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'kernels'):
         assert key in d, key
     assert d['n_gpus'] == 1 and d['steps'] == 3 and d['value'] > 0 and d['vs_baseline'] is None
-    assert set(d['roofline']) >= {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'}
+    assert set(d['roofline']) >= {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source'}
+    assert d['config']['batch_per_gpu'] in [r['batch'] for r in d['batch_sweep']]   # --batch auto is the default
     assert {k['kernel'] for k in d['kernels']} >= {'flash_fwd_kernel', 'sense_mix_kernel', 'add_layer_norm_kernel'}
 
 
