@@ -538,30 +538,29 @@ class SenseMixFn(torch.autograd.Function):
 def _sense_mix_backward_rebuild(ctx, qk, content, lse, key_weight, dout):
     """alpha rebuilt once by bp_sense_alpha from the saved LSE (two (B,k,S,S) 16-bit buffers), batched GEMMs,
     bp_softmax_bwd_causal in place, two thin GEMMs: the round-1 formulation, kept for key_weight / odd shapes."""
-    if True:
-        b, s, _, k, dk = qk.shape
-        alpha = sense_alpha(qk, ctx.scale, lse=lse)                               # (B,k,S,S)
-        weighted = alpha if key_weight is None else alpha * key_weight.unsqueeze(2).to(alpha.dtype)
-        g = dout.unsqueeze(1)                                                      # (B,1,S,d)
-        dcontent = None
-        if ctx.needs_input_grad[1]:
-            dcontent = torch.matmul(weighted.transpose(2, 3), g).transpose(1, 2)   # (B,S,k,d) view of (B,k,S,d)
-        dqk = None
-        if ctx.needs_input_grad[0]:
-            dalpha = torch.matmul(g, content.permute(0, 2, 3, 1))                  # (B,k,S_t,S_s)
-            if key_weight is not None:
-                dalpha = dalpha * key_weight.unsqueeze(2).to(dalpha.dtype)
-            dalpha = dalpha.contiguous()
-            if softmax_bwd_causal_supported(alpha):
-                ds = softmax_bwd_causal_(alpha, dalpha, ctx.scale)
-            else:
-                a32, d32 = alpha.float(), dalpha.float()
-                ds = (ctx.scale * a32 * (d32 - (a32 * d32).sum(-1, keepdim=True))).to(alpha.dtype)
-            q, kk = qk[:, :, 0].transpose(1, 2), qk[:, :, 1].transpose(1, 2)       # (B,k,S,dk)
-            dq = torch.matmul(ds, kk)
-            dkk = torch.matmul(ds.transpose(2, 3), q)
-            dqk = torch.stack([dq.transpose(1, 2), dkk.transpose(1, 2)], dim=2)   # (B,S,2,k,dk)
-        return dqk, dcontent, None, None
+    b, s, _, k, dk = qk.shape
+    alpha = sense_alpha(qk, ctx.scale, lse=lse)                               # (B,k,S,S)
+    weighted = alpha if key_weight is None else alpha * key_weight.unsqueeze(2).to(alpha.dtype)
+    g = dout.unsqueeze(1)                                                      # (B,1,S,d)
+    dcontent = None
+    if ctx.needs_input_grad[1]:
+        dcontent = torch.matmul(weighted.transpose(2, 3), g).transpose(1, 2)   # (B,S,k,d) view of (B,k,S,d)
+    dqk = None
+    if ctx.needs_input_grad[0]:
+        dalpha = torch.matmul(g, content.permute(0, 2, 3, 1))                  # (B,k,S_t,S_s)
+        if key_weight is not None:
+            dalpha = dalpha * key_weight.unsqueeze(2).to(dalpha.dtype)
+        dalpha = dalpha.contiguous()
+        if softmax_bwd_causal_supported(alpha):
+            ds = softmax_bwd_causal_(alpha, dalpha, ctx.scale)
+        else:
+            a32, d32 = alpha.float(), dalpha.float()
+            ds = (ctx.scale * a32 * (d32 - (a32 * d32).sum(-1, keepdim=True))).to(alpha.dtype)
+        q, kk = qk[:, :, 0].transpose(1, 2), qk[:, :, 1].transpose(1, 2)       # (B,k,S,dk)
+        dq = torch.matmul(ds, kk)
+        dkk = torch.matmul(ds.transpose(2, 3), q)
+        dqk = torch.stack([dq.transpose(1, 2), dkk.transpose(1, 2)], dim=2)   # (B,S,2,k,dk)
+    return dqk, dcontent, None, None
 
 
 def sense_mix_autograd(qk, content, softmax_scale=None, key_weight=None):

@@ -135,10 +135,6 @@ BP_DEV float xhalf(float x) { return __shfl_xor(x, 32); }
 // max / sum of x over the two half-waves (lanes l and l^32), result in both lanes, with ONE
 // v_permlane32_swap instead of an LDS round trip: the swap exchanges lanes 32..63 of its first
 // operand with lanes 0..31 of its second, so {r0, r1} hold {own, other} in one order or the other.
-#ifdef BP_DEBUG_NO_PERMLANE
-BP_DEV float xhalf_max(float x) { return fmaxf(x, __shfl_xor(x, 32)); }
-BP_DEV float xhalf_sum(float x) { return x + __shfl_xor(x, 32); }
-#else
 BP_DEV void xhalf_pair(float x, float &a, float &b) {
     const uint32_t u = as_u32(x);
     auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
@@ -156,7 +152,6 @@ BP_DEV float xhalf_sum(float x) {
     xhalf_pair(x, a, b);
     return a + b;
 }
-#endif
 
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;

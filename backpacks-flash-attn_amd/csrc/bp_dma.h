@@ -55,10 +55,6 @@ BP_DEV void dma4(const void *g, uint32_t lds_addr) {
 // Same, "saddr" form: wave-uniform 64-bit base in SGPRs + per-lane 32-bit BYTE offset.  The per-tile
 // address update then happens on the scalar unit (base += tile stride) and costs no VALU.
 BP_DEV void dma16_s(const uint16_t *uniform_base, uint32_t lane_byte_off, uint32_t lds_addr) {
-#ifdef BP_DEBUG_NO_SADDR
-    dma16(reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(uniform_base) + lane_byte_off), lds_addr);
-    return;
-#endif
     uint32_t keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
