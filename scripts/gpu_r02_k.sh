@@ -2,7 +2,7 @@
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 L=$GRAFT_REPO_ROOT/backpacks-flash-attn_amd/bp_hip
-timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_dropout.py -q -m gpu --timeout 900 -k "flash or dropout" 2>&1 | tail -5 > gpurun_out/t_r02_k.log
+timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_dropout.py tests/test_gpu_configs.py tests/test_gpu_model.py tests/test_gpu_backward.py -q -m gpu --timeout 900  2>&1 | tail -5 > gpurun_out/t_r02_k.log
 for rep in 1 2 3; do
 for v in _head ""; do
   for cfg in "1024 64" "1024 256" "512 128" "4096 16"; do

@@ -1,0 +1,480 @@
+// Fused attention forward for gfx950, LDS-DMA ring version: the fast path for 16-byte friendly
+// shapes (head_dim % 8 == 0, aligned rows) -- every shape the reference kernel accepts
+// (csrc/flash_attn/fmha_api.cpp:245).  Same math and tile algebra as flash_fwd.hip (bp_common.h):
+//   * K/V tiles (64 keys) go straight from global memory to a 2-slot LDS ring with
+//     global_load_lds_dwordx4: no VGPR staging, no ds_write pass, counted completion + ONE raw
+//     s_barrier per tile (bp_dma.h); K rows: power-of-two pitch + XOR slot swizzle, V rows: 64-B chunk
+//     swizzle, both applied on the DMA source address; every MFMA operand read is `lane base + immediate`.
+//   * TWO tile bodies.  The kernel is bound by the VALU stream of the softmax, not by MFMA or memory
+//     (DESIGN.md section 4), so the steady-state body carries the minimum: with the running reference
+//     maximum m of a row fixed, p = exp2(s*c - m*c) and the row sum need no row maximum at all -- one fma,
+//     one exp, one add and half a pack per score.  It is legal as long as no p overflows, and since
+//     p >= 0 the tile's row sum bounds every p from above: ONE wave-wide compare of the 32 partial sums
+//     against 2^14 (fp16) / 2^30 (bf16) validates the tile after the fact.  If it fails (a score jumped far
+//     above everything the row has seen), nothing has been accumulated yet; the EXACT body recomputes the
+//     tile from LDS with the textbook online-softmax step (true maximum, rescale of O and l).  The exact
+//     body also serves every tile that needs masking (sequence end, causal diagonal) and the first tile
+//     of a row, which sets m.  The reference keeps the exact form for every tile
+//     (csrc/flash_attn/src/fmha/softmax.h:238-251, fmha_fprop_kernel_1xN.h:429-444); results agree to
+//     rounding because softmax is invariant to the reference point.
+//   * in-kernel dropout (training; reference fmha_fprop_kernel_1xN.h:494-506): counter-based bits per
+//     (batch*head, query, key), see bp_philox.h; dropped probabilities are zeroed AFTER the row sum, the
+//     output is scaled by 1 / (1 - p) once in the epilogue.
+#include "bp_common.h"
+#include "bp_dma.h"
+#include "bp_kernels.h"
+#include "bp_philox.h"
+
+// waves per SIMD the register allocator must leave room for (512 VGPRs per SIMD lane): the trunk shapes
+// (head_dim <= 64) run four workgroups per CU (three with the Philox state of the dropout variant)
+#ifndef BP_FLASH_MINWAVES
+#define BP_FLASH_MINWAVES(NV, DROP) ((NV) <= 2 ? ((DROP) ? 3 : 4) : 1)
+#endif
+
+namespace bp {
+
+template <int KD, int NV, bool HAS_V>
+struct FlashDmaCfg {
+    static constexpr int BM = 128, BN = 64, NT = 256, NWAVE = 4, NSTAGE = 2;
+    static constexpr int KROW = KD <= 4 ? 128 : 256;
+    static constexpr int KSLOTS = KROW / 16;
+    static constexpr int VROW = NV * 64;
+    static constexpr int VCH = NV * 4;
+    static constexpr int KTILE = BN * KROW;
+    static constexpr int VTILE = HAS_V ? BN * VROW : 0;
+    static constexpr int STAGE = KTILE + VTILE;
+    static constexpr int K_DMA = KTILE / 1024 / NWAVE;            // 2 or 4 per wave per tile
+    static constexpr int V_DMA = HAS_V ? VTILE / 1024 / NWAVE : 0;  // 1..4
+    static constexpr int K_ROWS_PER_DMA = 1024 / KROW;
+};
+
+template <class ET> struct ProbLimit;   // largest tile row sum the fast body accepts (see header)
+template <> struct ProbLimit<BF16> { static constexpr float value = 1073741824.f; };   // 2^30
+template <> struct ProbLimit<F16> { static constexpr float value = 16384.f; };         // 2^14
+
+// The query tiles `qt0` and (if >= 0) `qt1` of (sample, head) `bh`, one after the other, as ONE stream through the
+// ring: per tile the whole online-softmax sweep over its key tiles.  What the two sweeps share is set up once
+// (sequence bounds, DMA descriptors, LDS read offsets); the second tile's Q fragments are requested into the first
+// tile's dead registers in front of its epilogue, and its first K/V tile is put in flight by the first sweep's last
+// ring step, so the second sweep starts on data that is already there (a per-workgroup timeline of the round-1
+// structure, scripts/probes/flash_timeline, showed 2.7 us waiting for Q and 1-1.6 us for the first tile in EACH
+// sweep plus a full barrier in between: 29 % of a causal S = 1024 workgroup's life).
+// FULLD: head_dim fills the K row pitch exactly (64 or 128): no predicated DMA pieces, no pad columns.
+template <class ET, int KD, int NV, bool HAS_V, bool FULLD, bool DROP>
+BP_DEV void flash_fwd_tiles(const FlashParams p, char *smem, const uint32_t lds0, const int bh, const int qt0, const int qt1) {
+    using C = FlashDmaCfg<KD, NV, HAS_V>;
+    using E = Elem<ET>;
+    constexpr float kLimit = ProbLimit<ET>::value;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int hh = lane >> 5;
+
+    const int batch = bh / p.h;
+    const int head = bh - batch * p.h;
+
+    int seq_q, seq_k;
+    int64_t q_off, k_off, v_off, o_off;
+    if (p.cu_q != nullptr) {
+        const int a = p.cu_q[batch], b = p.cu_q[batch + 1];
+        const int c = p.cu_k[batch], d = p.cu_k[batch + 1];
+        seq_q = b - a; seq_k = d - c;
+        q_off = a * p.q_rs; o_off = a * p.o_rs; k_off = c * p.k_rs; v_off = c * p.v_rs;
+    } else {
+        seq_q = p.max_sq; seq_k = p.max_sk;
+        q_off = batch * p.q_bs; o_off = batch * p.o_bs; k_off = batch * p.k_bs; v_off = batch * p.v_bs;
+    }
+    const bool valid0 = qt0 * C::BM < seq_q, valid1 = qt1 >= 0 && qt1 * C::BM < seq_q;
+    if (!valid0 && !valid1) return;
+
+    const uint16_t *qg = reinterpret_cast<const uint16_t *>(p.q) + q_off + (int64_t)head * p.q_hs;
+    const uint16_t *kg = reinterpret_cast<const uint16_t *>(p.k) + k_off + (int64_t)head * p.k_hs;
+    const uint16_t *vg = HAS_V ? reinterpret_cast<const uint16_t *>(p.v) + v_off + (int64_t)head * p.v_hs : nullptr;
+    const float c2 = p.scale_log2e;
+
+    // ---- Q fragments (B operand of S^T = K Q^T): requested here, waited for where the sweep starts ----------
+    u32x4 qf[KD];
+    auto request_q = [&](int qt) {
+        const int row_q = qt * C::BM + wave * 32 + l31;
+        const uint16_t *row = qg + (int64_t)min(row_q, seq_q - 1) * p.q_rs;
+#pragma unroll
+        for (int s = 0; s < KD; ++s) {
+            const int col = 16 * s + 8 * hh;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (FULLD || col < p.d) v = ld_global_16B(row + col);
+            qf[s] = v;
+        }
+    };
+    request_q(valid0 ? qt0 : qt1);
+
+    // ---- what depends on the query tile: set at the top of each sweep ---------------------------------------
+    int qt = 0, nkb = 0, q0 = 0, my_q = 0, my_nkb = 0, my_clean_end = 0;
+    bool wave_has_rows = false;
+
+    // K pad slots (head_dim not a multiple of 16, or pitch wider than the row) are never written by
+    // the DMA and meet zero Q columns in the MFMA: they must hold finite values -> zero them once.
+    if (!FULLD) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (int off = tid * 16; off < C::NSTAGE * C::STAGE; off += C::NT * 16) lds_write_16B(smem, off, z);
+        __syncthreads();
+    }
+
+    DropoutStream rng = {0u, 0u};
+    if (DROP) rng = dropout_stream(p.rng_state, (uint32_t)bh);
+
+    // ---- per-lane DMA source descriptors: tile row / column of the 16-B chunk this lane moves ----------
+    int k_row[C::K_DMA], k_col[C::K_DMA];
+    uint32_t k_voff[C::K_DMA];
+#pragma unroll
+    for (int j = 0; j < C::K_DMA; ++j) {
+        const int row = (wave * C::K_DMA + j) * C::K_ROWS_PER_DMA + lane / C::KSLOTS;
+        k_row[j] = row;
+        k_col[j] = ((lane % C::KSLOTS) ^ k_swz<C::KROW>(row)) * 8;
+        k_voff[j] = (uint32_t)(row * p.k_rs + k_col[j]) * 2u;
+    }
+    int v_row[HAS_V ? C::V_DMA : 1], v_col[HAS_V ? C::V_DMA : 1];
+    uint32_t v_voff[HAS_V ? C::V_DMA : 1];
+    if (HAS_V) {
+#pragma unroll
+        for (int j = 0; j < C::V_DMA; ++j) {
+            const int c = (wave * C::V_DMA + j) * 64 + lane;   // linear 16-B chunk of the tile
+            const int row = c / C::VCH, stored = c - row * C::VCH;
+            int c64 = stored >> 2;
+            if (NV == 2) c64 ^= (row >> 1) & 1;
+            if (NV == 4) c64 ^= row & 3;
+            v_row[j] = row;
+            v_col[j] = ((c64 << 2) | (stored & 3)) * 8;
+            v_voff[j] = (uint32_t)(row * p.v_rs + v_col[j]) * 2u;
+        }
+    }
+    // Scalar tile base + constant per-lane byte offset -> no VALU at all.  The only partial tile a sweep can meet is
+    // the sequence's last one; its rows are clamped to the final valid key (those keys are masked later) through a
+    // second, precomputed offset set and a uniform select.
+    const int kb_partial = (seq_k % C::BN) != 0 ? seq_k / C::BN : -1;
+    const int last_row = seq_k - 1 - (seq_k / C::BN) * C::BN;
+    uint32_t k_voff_p[C::K_DMA], v_voff_p[HAS_V ? C::V_DMA : 1];
+#pragma unroll
+    for (int j = 0; j < C::K_DMA; ++j) k_voff_p[j] = (uint32_t)(min(k_row[j], last_row) * p.k_rs + k_col[j]) * 2u;
+    if (HAS_V) {
+#pragma unroll
+        for (int j = 0; j < C::V_DMA; ++j) v_voff_p[j] = (uint32_t)(min(v_row[j], last_row) * p.v_rs + v_col[j]) * 2u;
+    }
+    const int64_t k_tile_stride = (int64_t)C::BN * p.k_rs, v_tile_stride = (int64_t)C::BN * p.v_rs;
+    const uint16_t *kt = kg, *vt = vg;   // tile kb of the NEXT issue (tiles are issued in order 0, 1, 2, ...)
+    auto issue = [&](int kb) {
+        // (readfirstlane: inside the per-lane predicate of the !FULLD case hipcc may hold the uniform address in a VGPR)
+        const uint32_t stage = __builtin_amdgcn_readfirstlane(lds0 + (kb & 1) * C::STAGE);
+        const bool partial = kb == kb_partial;
+#pragma unroll
+        for (int j = 0; j < C::K_DMA; ++j)
+            if (FULLD || k_col[j] < p.d)
+                dma16_s(kt, partial ? k_voff_p[j] : k_voff[j],
+                        __builtin_amdgcn_readfirstlane(stage + (wave * C::K_DMA + j) * 1024));
+        if (HAS_V) {
+#pragma unroll
+            for (int j = 0; j < C::V_DMA; ++j)
+                if (FULLD || v_col[j] < p.d)
+                    dma16_s(vt, partial ? v_voff_p[j] : v_voff[j],
+                            __builtin_amdgcn_readfirstlane(stage + C::KTILE + (wave * C::V_DMA + j) * 1024));
+            vt += v_tile_stride;
+        }
+        kt += k_tile_stride;
+    };
+
+    f32x16 acc[HAS_V ? NV : 1];
+    float m_run = -INFINITY;   // reference maximum of my row (raw score units)
+    float mc = 0.f;            // m_run * c2, 0 while the row has seen no key
+    float l_run = 0.f;         // my half-wave's share of sum p
+
+    int k_read_off[KD];
+#pragma unroll
+    for (int s = 0; s < KD; ++s) k_read_off[s] = l31 * C::KROW + (((2 * s + hh) ^ k_swz<C::KROW>(l31)) * 16);
+    int v_read_off[HAS_V ? NV : 1];
+    if (HAS_V) {
+        const int v_row_lane = 4 * hh + ((lane & 15) >> 2);
+        const int v_ch_lane = ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1);
+#pragma unroll
+        for (int n = 0; n < NV; ++n) v_read_off[n] = v_lds_off<NV>(v_row_lane, n * 4 + v_ch_lane) + (lane & 1) * 8;
+    }
+
+    // S^T of one 32-key half of the tile
+    auto scores = [&](const char *kbuf, int kk) {
+        f32x16 s_;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KD; ++s) {
+            const u32x4 a = lds_read_16B(kbuf, k_read_off[s] + kk * 32 * C::KROW);
+            s_ = E::mfma(a, qf[s], s_);
+        }
+        return s_;
+    };
+    // p (in place) = exp2(s*c2 - mc), returns my share of the row sum
+    auto exponentiate = [&](f32x16 (&st)[2]) {
+        float rs0 = 0.f, rs1 = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float x0 = fast_exp2(fmaf(st[kk][r], c2, -mc));
+                const float x1 = fast_exp2(fmaf(st[kk][r + 1], c2, -mc));
+                st[kk][r] = x0;
+                st[kk][r + 1] = x1;
+                rs0 += x0;
+                rs1 += x1;
+            }
+        return rs0 + rs1;
+    };
+    // dropout (after the row sum), then O^T += V^T P^T
+    auto accumulate = [&](int kb, const char *vbuf, f32x16 (&st)[2], bool skip_hi) {
+        if (!HAS_V) return;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (kk == 1 && skip_hi) continue;
+            if (DROP) {
+                const uint32_t keep = dropout_keep_rowlane(rng, p.drop_thr, (uint32_t)my_q,
+                                                           (uint32_t)(kb * C::BN + kk * 32), hh);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (!((keep >> r) & 1u)) st[kk][r] = 0.f;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 pf;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pf[i] = E::pack2(st[kk][ks * 8 + 2 * i], st[kk][ks * 8 + 2 * i + 1]);
+                const int rows = (kk * 32 + ks * 16) * C::VROW;
+#pragma unroll
+                for (int n = 0; n < NV; ++n) {
+                    const u32x2 lo = lds_read_tr16_8B(vbuf, v_read_off[n] + rows);
+                    const u32x2 hi = lds_read_tr16_8B(vbuf, v_read_off[n] + rows + 8 * C::VROW);
+                    const u32x4 a = {lo[0], lo[1], hi[0], hi[1]};
+                    acc[n] = E::mfma(a, pf, acc[n]);
+                }
+            }
+        }
+    };
+
+    // Textbook online-softmax bookkeeping of one tile, on raw scores (in place): mask what my row may not see,
+    // take the true tile maximum, move the row's reference maximum and rescale O and l accordingly.
+    auto online_max_step = [&](int kb, f32x16 (&st)[2]) {
+        // register r of half kk holds key base + kk*32 + (r&3) + 8*(r>>2) + 4*hh: dead iff that exceeds the last
+        // visible key of my row -> ONE per-lane limit against compile-time constants
+        int last = seq_k - 1;
+        if (p.causal) last = min(last, my_q);
+        int lim = last - kb * C::BN - 4 * hh;
+        // (opaque on purpose: otherwise hipcc speculates the 32 compares out of this rarely taken branch into every tile)
+        asm volatile("" : "+v"(lim));
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kk * 32 + (r & 3) + 8 * (r >> 2) > lim) st[kk][r] = -INFINITY;
+        // row max: four independent chains, then the other half-wave
+        float mxa = st[0][0], mxb = st[0][8], mxc = st[1][0], mxd = st[1][8];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) {
+            mxa = fmaxf(mxa, st[0][r]);
+            mxb = fmaxf(mxb, st[0][8 + r]);
+            mxc = fmaxf(mxc, st[1][r]);
+            mxd = fmaxf(mxd, st[1][8 + r]);
+        }
+        const float mt = xhalf_max(fmaxf(fmaxf(mxa, mxb), fmaxf(mxc, mxd)));
+        const float m_new = fmaxf(mt, m_run);
+        // alpha = 1 exactly for a row whose maximum did not move; exp2(-inf - x) = 0 for a fresh row, whose (zero) O
+        // and l are "rescaled" harmlessly
+        const float mc_new = (m_new == -INFINITY) ? 0.f : m_new * c2;
+        const float alpha = fast_exp2(m_run * c2 - mc_new);
+        l_run *= alpha;
+        if (HAS_V) {
+#pragma unroll
+            for (int n = 0; n < NV; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[n][r] *= alpha;
+        }
+        m_run = m_new;
+        mc = mc_new;
+    };
+
+    // One key tile.  `exact`: the tile needs masking (sequence end, causal diagonal) or is the first of the row ->
+    // the textbook step above runs before the exponentials.  Otherwise the steady-state form: the reference
+    // maximum stays, and if its overflow test fails afterwards (rare; nothing accumulated yet) the SAME code runs
+    // once more on scores recomputed from LDS, the textbook way.
+    auto tile = [&](int kb, const char *kbuf, const char *vbuf, bool exact) {
+        f32x16 st[2];
+        float rs;
+        for (;;) {
+            st[0] = scores(kbuf, 0);
+            st[1] = scores(kbuf, 1);
+            if (__builtin_expect(exact, 0)) online_max_step(kb, st);
+            rs = exponentiate(st);
+            if (__builtin_expect(exact || __all(rs <= kLimit), 1)) break;   // inf and NaN fail the test too
+            exact = true;
+        }
+        l_run += rs;
+        // second 32-key half entirely above my rows (diagonal tile): all its p are 0
+        accumulate(kb, vbuf, st, p.causal && (kb * C::BN + 32 > q0 + 31));
+    };
+
+    bool chained = false;   // the coming sweep's first K/V tile is already in flight
+    bool ran = false;       // a sweep has used the ring before
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        if (!(pass == 0 ? valid0 : valid1)) continue;
+        qt = pass == 0 ? qt0 : qt1;
+        int k_end = seq_k;
+        if (p.causal) k_end = min(seq_k, qt * C::BM + C::BM);
+        nkb = (k_end + C::BN - 1) / C::BN;
+        q0 = qt * C::BM + wave * 32;
+        my_q = q0 + l31;
+        wave_has_rows = q0 < seq_q;
+        // Which key tiles this wave computes, and which of them the fast body may take: a tile is "clean" when
+        // every key exists and every (query, key) pair of my 32 rows is visible.
+        my_nkb = !wave_has_rows ? 0 : p.causal ? min(nkb, (q0 + 31) / C::BN + 1) : nkb;
+        my_clean_end = p.causal ? min(seq_k / C::BN, (q0 + 1) / C::BN) : seq_k / C::BN;
+        // may this sweep's last ring step start the next sweep's stream?  (an even tile count leaves slot 0 free)
+        const bool chain = pass == 0 && valid0 && valid1 && nkb > 0 && (nkb & 1) == 0;
+
+        if (!chained) {
+            if (ran) __syncthreads();   // every wave is done with the ring before this sweep's DMA refills it
+            kt = kg;
+            vt = vg;
+            if (nkb > 0) issue(0);
+        }
+        chained = false;
+        ran = true;
+        // The Q fragments were requested earlier (in front of the descriptors / of the previous epilogue); make them
+        // "arrive" here, behind the first tile's DMA issue (settle, bp_common.h: without it their wait lands inside
+        // the loop and drains the ring).
+#pragma unroll
+        for (int s = 0; s < KD; ++s) settle(qf[s]);
+#pragma unroll
+        for (int n = 0; n < (HAS_V ? NV : 1); ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+        m_run = -INFINITY;
+        mc = 0.f;
+        l_run = 0.f;
+
+        // One ring step; SLOT is the ring slot as a compile-time constant (the loop is unrolled by the ring depth),
+        // so the LDS addresses of all operand reads fold into instruction offsets.
+        auto ring_step = [&](int kb, auto SLOT) {
+            constexpr int kSlot = decltype(SLOT)::value;
+            wait_vmcnt<0>();                    // my share of tile kb has landed ...
+            __builtin_amdgcn_s_barrier();       // ... so has everybody's; all waves are done reading the other slot
+            if (kb + 1 < nkb) {
+                issue(kb + 1);
+            } else if (chain) {                 // last step: the other slot is slot 0, where the next sweep starts
+                kt = kg;
+                vt = vg;
+                issue(0);
+            }
+            if (kb < my_nkb) {
+                const char *kbuf = smem + kSlot * C::STAGE;
+                const char *vbuf = kbuf + C::KTILE;
+                tile(kb, kbuf, vbuf, kb == 0 || kb >= my_clean_end);
+            }
+        };
+        for (int kb = 0; kb < nkb; kb += 2) {
+            ring_step(kb, std::integral_constant<int, 0>{});
+            if (kb + 1 < nkb) ring_step(kb + 1, std::integral_constant<int, 1>{});
+        }
+        chained = chain;
+
+        const float l_tot = xhalf_sum(l_run);
+        const float mc_done = mc;
+        const int q_done = my_q;
+        // the next sweep's Q fragments go into this sweep's (now dead) fragment registers while the epilogue runs
+        if (pass == 0 && valid1) request_q(qt1);
+
+        if (!wave_has_rows) continue;
+        float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+        if (DROP) inv *= p.drop_scale;
+        if (q_done < seq_q) {
+            if (hh == 0 && p.lse != nullptr) {
+                const float lse = l_tot > 0.f ? (mc_done + fast_log2(l_tot)) * kLn2 : -INFINITY;
+                p.lse[((int64_t)batch * p.h + head) * p.lse_stride + q_done] = lse;
+            }
+            if (HAS_V) {
+                uint16_t *og = reinterpret_cast<uint16_t *>(p.o) + o_off + (int64_t)q_done * p.o_rs + (int64_t)head * p.o_hs;
+#pragma unroll
+                for (int n = 0; n < NV; ++n)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int d0 = n * 32 + 8 * g + 4 * hh;
+                        if (d0 < p.d) {
+                            u32x2 w = {E::pack2(acc[n][4 * g + 0] * inv, acc[n][4 * g + 1] * inv),
+                                       E::pack2(acc[n][4 * g + 2] * inv, acc[n][4 * g + 3] * inv)};
+                            *reinterpret_cast<u32x2 *>(og + d0) = w;
+                        }
+                    }
+            }
+        }
+    }
+}
+
+// Work order.  The dispatcher hands workgroups to the CUs of an XCD strictly round-robin and IN ORDER: block
+// i+1 is not placed before block i, and block i waits for a free slot on ITS CU even when other CUs idle
+// (scripts/probes/dispatch_order.hip).  With causal tiles of 1..n key blocks in block order, a CU keeps getting
+// the same tile length and the short ones wait for the long ones: 64 time units instead of 36 for S = 1024 in a
+// model of that dispatcher, and 8.3 vs 5.9 ms in the probe.  So a causal workgroup takes TWO query tiles of its
+// (sample, head), the heaviest remaining and the lightest (t and n-1-t): every workgroup then carries the same
+// n+1 key blocks, nothing waits, and both tiles still belong to one group, i.e. one XCD's L2 holds their K/V.
+template <class ET, int KD, int NV, bool HAS_V, bool FULLD, bool DROP>
+__global__ __launch_bounds__(256, BP_FLASH_MINWAVES(NV, DROP)) void flash_fwd_dma_kernel(const FlashParams p) {
+    using C = FlashDmaCfg<KD, NV, HAS_V>;
+    __shared__ __attribute__((aligned(16))) char smem[C::NSTAGE * C::STAGE];
+    const uint32_t lds0 = lds_base_addr(smem);
+    const int per_group = p.pair ? (p.n_qtiles + 1) / 2 : p.n_qtiles;
+    int bh, slot;
+    if (!xcd_map(blockIdx.x, p.b * p.h, per_group, bh, slot)) return;
+    const int heavy = p.n_qtiles - 1 - slot;
+    flash_fwd_tiles<ET, KD, NV, HAS_V, FULLD, DROP>(p, smem, lds0, bh, heavy, (p.pair && slot != heavy) ? slot : -1);
+}
+
+template <class ET, int KD, int NV, bool HAS_V, bool FULLD, bool DROP>
+static hipError_t launch_one(const FlashParams &p, hipStream_t stream) {
+    const int grid = xcd_grid(p.b * p.h, p.pair ? (p.n_qtiles + 1) / 2 : p.n_qtiles);
+    hipLaunchKernelGGL((flash_fwd_dma_kernel<ET, KD, NV, HAS_V, FULLD, DROP>), dim3(grid), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+template <class ET, int KD, int NV, bool HAS_V, bool DROP>
+static hipError_t launch_kd(const FlashParams &p, hipStream_t stream) {
+    using C = FlashDmaCfg<KD, NV, HAS_V>;
+    if constexpr (KD == 4 || KD == 8) {
+        if (p.d * 2 == C::KROW) return launch_one<ET, KD, NV, HAS_V, true, DROP>(p, stream);
+    }
+    return launch_one<ET, KD, NV, HAS_V, false, DROP>(p, stream);
+}
+
+template <class ET, bool HAS_V, bool DROP>
+static hipError_t launch_dim(const FlashParams &p, hipStream_t stream) {
+    switch ((p.d + 15) / 16) {
+        case 1: return launch_kd<ET, 1, 1, HAS_V, DROP>(p, stream);
+        case 2: return launch_kd<ET, 2, 1, HAS_V, DROP>(p, stream);
+        case 3: return launch_kd<ET, 3, 2, HAS_V, DROP>(p, stream);
+        case 4: return launch_kd<ET, 4, 2, HAS_V, DROP>(p, stream);
+        case 5: return launch_kd<ET, 5, 3, HAS_V, DROP>(p, stream);
+        case 6: return launch_kd<ET, 6, 3, HAS_V, DROP>(p, stream);
+        case 7: return launch_kd<ET, 7, 4, HAS_V, DROP>(p, stream);
+        default: return launch_kd<ET, 8, 4, HAS_V, DROP>(p, stream);
+    }
+}
+
+template <class ET>
+static hipError_t launch_et(const FlashParams &p, hipStream_t stream) {
+    if (p.v == nullptr) return launch_dim<ET, false, false>(p, stream);
+    if (p.drop_thr != 0u) return launch_dim<ET, true, true>(p, stream);
+    return launch_dim<ET, true, false>(p, stream);
+}
+
+// Requires head_dim % 8 == 0, 16-byte aligned bases, strides multiples of 8, seq_k >= 1 per sequence
+// handled inside (nkb == 0 issues nothing).
+hipError_t launch_flash_fwd_dma(const FlashParams &p, int dtype, hipStream_t stream) {
+    return dtype == 1 ? launch_et<BF16>(p, stream) : launch_et<F16>(p, stream);
+}
+
+}  // namespace bp
