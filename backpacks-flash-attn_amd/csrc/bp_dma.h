@@ -67,6 +67,20 @@ BP_DEV void dma16_s(const uint16_t *uniform_base, uint32_t lane_byte_off, uint32
         : "memory");
 }
 
+// dma16_s for data that is read once (the content stream of the sense mix): non-temporal hint.
+BP_DEV void dma16_s_nt(const uint16_t *uniform_base, uint32_t lane_byte_off, uint32_t lds_addr) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2 nt\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane_byte_off), "s"(uniform_base), "s"(lds_addr)
+        : "memory");
+}
+
 BP_DEV uint32_t lds_base_addr(char *smem) { return (uint32_t)(uintptr_t)(lmem_v *)smem; }
 
 template <int N> BP_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }

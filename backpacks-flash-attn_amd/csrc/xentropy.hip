@@ -46,8 +46,9 @@ template <class H> struct XeLoad16 {
     }
     static BP_DEV float one(const void *p) { return Elem<H>::lo_f32(*reinterpret_cast<const uint16_t *>(p)); }
     static BP_DEV void store(void *p, const float (&v)[8]) {
-        *reinterpret_cast<u32x4 *>(p) = u32x4{Elem<H>::pack2(v[0], v[1]), Elem<H>::pack2(v[2], v[3]),
-                                              Elem<H>::pack2(v[4], v[5]), Elem<H>::pack2(v[6], v[7])};
+        const u32x4 w = u32x4{Elem<H>::pack2(v[0], v[1]), Elem<H>::pack2(v[2], v[3]),
+                              Elem<H>::pack2(v[4], v[5]), Elem<H>::pack2(v[6], v[7])};
+        *reinterpret_cast<u32x4 *>(p) = w;   // (non-temporal here: +5 % time -- the line was just read, r02_p)
     }
     static BP_DEV void store_one(void *p, float x) { *reinterpret_cast<uint16_t *>(p) = Elem<H>::from_float(x); }
 };
