@@ -273,17 +273,19 @@ def test_sense_mix_backward(shape, weighted):
         assert err <= 2 * base + 1e-3 * max(1.0, r.abs().max().item()), (name, err, base)
 
 
-@pytest.mark.parametrize('shape', [(2, 1024, 16, 48, 768), (1, 333, 16, 48, 768), (2, 512, 64, 16, 640), (3, 256, 4, 96, 384)])
+@pytest.mark.parametrize('shape', [(2, 1024, 16, 48, 768), (1, 333, 16, 48, 768), (2, 512, 64, 16, 640), (3, 256, 4, 96, 384),
+                                   (2, 640, 16, 48, 768, 'fp16'), (1, 2048, 16, 48, 256)])
 def test_sense_mix_backward_fused_needs_no_alpha_sized_buffer(shape):
     """The fused backward (bp_sense_mix_dc + slab GEMM + bp_sense_dq_dk) at real sizes: gradients against the fp32
     oracle's autograd with the eager-bf16 autograd as yardstick, and NO (B,k,S,S) allocation: the peak memory of the
     backward stays below one alpha-sized 16-bit tensor on top of inputs, outputs and the (B, S*k, 128) slab."""
     bp = _bp()
-    b, s, k, dk, d = shape
+    b, s, k, dk, d = shape[:5]
+    dt = torch.float16 if shape[5:] == ('fp16',) else torch.bfloat16
     torch.manual_seed(17)
-    qk = (torch.randn(b, s, 2, k, dk) * 0.8).bfloat16()
-    c = torch.randn(b, s, k, d).bfloat16()
-    dout = torch.randn(b, s, d).bfloat16()
+    qk = (torch.randn(b, s, 2, k, dk) * 0.8).to(dt)
+    c = torch.randn(b, s, k, d).to(dt)
+    dout = torch.randn(b, s, d).to(dt)
     ref = _mix_grads(qk.float(), c.float(), dout.float(), None, fused=False)
     eager = _mix_grads(qk, c, dout, None, fused=False)
     qk_d, c_d, dout_d = qk.to(DEV).requires_grad_(), c.to(DEV).requires_grad_(), dout.to(DEV)
