@@ -56,6 +56,11 @@ template <> struct Elem<BF16> {
     }
     static BP_DEV float lo_f32(uint32_t w) { return as_f32(w << 16); }
     static BP_DEV float hi_f32(uint32_t w) { return as_f32(w & 0xffff0000u); }
+    // c + lo + hi of a packed pair in ONE VALU instruction (v_dot2c_f32_bf16 against {1, 1})
+    static BP_DEV float add_pair(uint32_t w, float c) {
+        const bf16x2 one = {(__bf16)1.0f, (__bf16)1.0f};
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w), one, c, false);
+    }
 };
 
 template <> struct Elem<F16> {
@@ -72,6 +77,10 @@ template <> struct Elem<F16> {
     }
     static BP_DEV float lo_f32(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu)); }
     static BP_DEV float hi_f32(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
+    static BP_DEV float add_pair(uint32_t w, float c) {   // v_dot2c_f32_f16 against {1, 1}
+        const f16x2 one = {(_Float16)1.0f, (_Float16)1.0f};
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, w), one, c, false);
+    }
 };
 
 // 8 consecutive 16-bit elements as one 16-byte global load (pointer must be 16-B aligned).

@@ -17,6 +17,9 @@
 //     of a row, which sets m.  The reference keeps the exact form for every tile
 //     (csrc/flash_attn/src/fmha/softmax.h:238-251, fmha_fprop_kernel_1xN.h:429-444); results agree to
 //     rounding because softmax is invariant to the reference point.
+//   * without dropout, P is rounded to 16 bit right behind the exponential and the row sum runs over the rounded
+//     pairs (v_dot2c_f32_{bf16,f16} against {1, 1}): one VALU instruction per two scores, and the normaliser
+//     is the sum of exactly the values that multiply V.
 //   * in-kernel dropout (training; reference fmha_fprop_kernel_1xN.h:494-506): counter-based bits per
 //     (batch*head, query, key), see bp_philox.h; dropped probabilities are zeroed AFTER the row sum, the
 //     output is scaled by 1 / (1 - p) once in the epilogue.
@@ -233,6 +236,46 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
             }
         return rs0 + rs1;
     };
+    // Without dropout P is rounded to 16 bit right behind the exponential and the row sum is taken over the ROUNDED
+    // pairs, one v_dot2c_f32_{bf16,f16} per two scores instead of two adds: the sum then normalises exactly the
+    // values that multiply V, and the VALU stream this kernel is bound by is 16 instructions per tile shorter.
+    constexpr bool PACKED_SUM = HAS_V && !DROP;
+    u32x4 pf[2][2];   // [32-key half][16-key step]
+    auto exponentiate_packed = [&](f32x16 (&st)[2]) {
+        float rs0 = 0.f, rs1 = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = ks * 8 + 2 * i;
+                    const float x0 = fast_exp2(fmaf(st[kk][r], c2, -mc));
+                    const float x1 = fast_exp2(fmaf(st[kk][r + 1], c2, -mc));
+                    const uint32_t w = E::pack2(x0, x1);
+                    pf[kk][ks][i] = w;
+                    if (i & 1) rs1 = E::add_pair(w, rs1);
+                    else rs0 = E::add_pair(w, rs0);
+                }
+        return rs0 + rs1;
+    };
+    auto accumulate_packed = [&](const char *vbuf, bool skip_hi) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (kk == 1 && skip_hi) continue;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int rows = (kk * 32 + ks * 16) * C::VROW;
+#pragma unroll
+                for (int n = 0; n < NV; ++n) {
+                    const u32x2 lo = lds_read_tr16_8B(vbuf, v_read_off[n] + rows);
+                    const u32x2 hi = lds_read_tr16_8B(vbuf, v_read_off[n] + rows + 8 * C::VROW);
+                    const u32x4 a = {lo[0], lo[1], hi[0], hi[1]};
+                    acc[n] = E::mfma(a, pf[kk][ks], acc[n]);
+                }
+            }
+        }
+    };
     // dropout (after the row sum), then O^T += V^T P^T
     auto accumulate = [&](int kb, const char *vbuf, f32x16 (&st)[2], bool skip_hi) {
         if (!HAS_V) return;
@@ -315,13 +358,15 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
             st[0] = scores(kbuf, 0);
             st[1] = scores(kbuf, 1);
             if (__builtin_expect(exact, 0)) online_max_step(kb, st);
-            rs = exponentiate(st);
+            rs = PACKED_SUM ? exponentiate_packed(st) : exponentiate(st);
             if (__builtin_expect(exact || __all(rs <= kLimit), 1)) break;   // inf and NaN fail the test too
             exact = true;
         }
         l_run += rs;
         // second 32-key half entirely above my rows (diagonal tile): all its p are 0
-        accumulate(kb, vbuf, st, p.causal && (kb * C::BN + 32 > q0 + 31));
+        const bool skip_hi = p.causal && (kb * C::BN + 32 > q0 + 31);
+        if (PACKED_SUM) accumulate_packed(vbuf, skip_hi);
+        else accumulate(kb, vbuf, st, skip_hi);
     };
 
     if (nkb > 0) issue(0);
