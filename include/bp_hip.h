@@ -7,7 +7,10 @@
  * and its Backpack-specific ops are eager ATen calls (training/src/models/backpack.py:107-122,313).
  * Every entry point below names the reference interface it replaces.  All of them
  *   - take raw DEVICE pointers, explicit sizes and int64 ELEMENT strides (no torch types),
- *   - allocate nothing and keep no state (re-entrant; scratch is passed in by the caller),
+ *   - allocate nothing and keep no caller-visible state (re-entrant; scratch is passed in by the caller).  The one
+ *     piece of internal state: bp_sense_mix* / bp_sense_mix_dc launch persistent workgroups that pull jobs from
+ *     ticket queues kept in a ring of 64-byte device records owned by the library (one record per launch in
+ *     flight, consecutive launches take consecutive records, each launch leaves its record zeroed),
  *   - enqueue on the given hipStream_t and return without synchronising,
  *   - return 0 on success or a negative BP_ERR_* (the Python layer raises RuntimeError, which
  *     is what TORCH_CHECK failures surface as in the reference: fmha_api.cpp:206-250).
