@@ -175,6 +175,15 @@ BP_DEV bool xcd_map(int block, int ngroups, int per_group, int &group, int &item
     item = slot % per_group;
     return group < ngroups;
 }
+// Persistent sense-mix launches (forward and dC): jobs of queue q (one queue per XCD), heaviest query tile first.  A group is a (sample, column chunk) pair; ALL chunks
+// of a sample go to the queue sample mod 8, so the workgroups that stream the sample's K rows share one L2
+// (-2 % at B = 64 / 128 against group mod 8, r02_u).
+BP_DEV int mix_queue_groups(int b, int n_chunks, int q) { return b > q ? ((b - q + 7) / 8) * n_chunks : 0; }
+BP_DEV int mix_queue_group(int n_chunks, int q, int local) {
+    const int bl = local / n_chunks;
+    return (bl * 8 + q) * n_chunks + (local - bl * n_chunks);
+}
+
 inline int xcd_grid(int ngroups, int per_group) { return ((ngroups + 7) / 8) * 8 * per_group; }
 
 }  // namespace bp

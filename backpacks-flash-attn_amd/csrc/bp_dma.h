@@ -81,6 +81,20 @@ BP_DEV void dma16_s_nt(const uint16_t *uniform_base, uint32_t lane_byte_off, uin
         : "memory");
 }
 
+// Plain global loads the compiler does not wait for: the caller owns the completion (an `s_waitcnt vmcnt(N)` that
+// accounts for everything issued after them, then a pin on the result, before the first use).  Lets per-sense
+// operands be requested a ring step ahead without the compiler's own `vmcnt(0)` draining the DMA ring.
+BP_DEV u32x4 ld_global_16B_async(const uint16_t *p) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+BP_DEV float ld_global_f32_async(const float *p) {
+    float v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
 BP_DEV uint32_t lds_base_addr(char *smem) { return (uint32_t)(uintptr_t)(lmem_v *)smem; }
 
 template <int N> BP_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }

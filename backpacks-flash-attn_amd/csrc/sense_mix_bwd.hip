@@ -98,13 +98,12 @@ __global__ __launch_bounds__(512) void sense_mix_dc_kernel(const MixBwdParams p)
         for (int t = 0; t < 8; ++t) {
             const int q = (my_xcd + t) & 7;
             if (exhausted & (1u << q)) continue;
-            const int ngroups = p.b * p.n_chunks;
-            const int groups = ngroups > q ? (ngroups - q + 7) / 8 : 0;
+            const int groups = mix_queue_groups(p.b, p.n_chunks, q);
             const int njobs = groups * p.n_ktiles;
             const int idx = njobs > 0 ? (int)atomicAdd(&queues->ticket[q], 1u) : njobs;
             if (idx < njobs) {
                 const int slot = idx / groups;
-                const int grp = (idx - slot * groups) * 8 + q;
+                const int grp = mix_queue_group(p.n_chunks, q, idx - slot * groups);
                 return grp * 256 + slot;
             }
             exhausted |= 1u << q;

@@ -53,12 +53,6 @@ struct MixDmaCfg {
     static constexpr int SMEM = JOB_OFF + 16;
 };
 
-// jobs of queue q: groups g = q, q+8, ... ; heaviest query tile first
-BP_DEV int mix_queue_groups(const MixParams &p, int q) {
-    const int ngroups = p.b * p.n_chunks;
-    return ngroups > q ? (ngroups - q + 7) / 8 : 0;
-}
-
 template <class ET, int KD, bool FULL, bool WEIGHTED>
 __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
     using C = MixDmaCfg<KD, WEIGHTED>;
@@ -120,19 +114,14 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
         for (int t = 0; t < 8; ++t) {
             const int q = (my_xcd + t) & 7;
             if (exhausted & (1u << q)) continue;
-            const int groups = mix_queue_groups(p, q);
+            const int groups = mix_queue_groups(p.b, p.n_chunks, q);
             const int njobs = groups * p.n_qtiles;
             const int idx = njobs > 0 ? (int)atomicAdd(&queues->ticket[q], 1u) : njobs;
             if (idx < njobs) {
-#ifndef BP_MIX_GROUP_MAJOR   // all groups' heaviest tiles first
+                // all groups' heaviest tiles first (a group's tiles together, so that its C slab is re-read while it might
+                // still be cached, gained nothing: 1.32 / 1.34 ms against 1.29 / 1.28 ms at B = 64, same fetch traffic, r02_e)
                 const int slot = idx / groups;
-                const int grp = (idx - slot * groups) * 8 + q;
-#else   // a group's tiles together (its C slab re-read while it might still be cached): no gain measured, r02_e:
-        // 1.32 / 1.34 ms against 1.29 / 1.28 ms at B = 64, same 5.9 GB of fetch traffic
-                const int gl = idx / p.n_qtiles;
-                const int slot = idx - gl * p.n_qtiles;
-                const int grp = gl * 8 + q;
-#endif
+                const int grp = mix_queue_group(p.n_chunks, q, idx - slot * groups);
                 return grp * 256 + (p.n_qtiles - 1 - slot);
             }
             exhausted |= 1u << q;
@@ -230,6 +219,30 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
                 qf[s] = v;
             }
             lse2 = p.lse[((int64_t)batch * p.nsenses + l) * p.lse_stride + my_q_clamped] * kLog2e;
+        };
+
+        // The same for the NEXT sense, requested at the start of a sense's last ring step and adopted behind it: the
+        // loads are older than that step's DMA pieces, so the ring's own counted wait covers them and no
+        // compiler-placed vmcnt(0) stalls the wave once per sense (a quarter of the steps of a light query tile).
+        u32x4 qn[KD];
+        float lse_n = 0.f;
+#pragma unroll
+        for (int s = 0; s < KD; ++s) qn[s] = u32x4{0u, 0u, 0u, 0u};
+        auto request_q = [&](int l) {
+            const uint16_t *row = qg + (int64_t)my_q_clamped * p.qk_rs + (int64_t)l * p.qk_ss;
+#pragma unroll
+            for (int s = 0; s < KD; ++s) qn[s] = ld_global_16B_async(row + min(16 * s + 8 * hh, p.dk - 8));
+            lse_n = ld_global_f32_async(p.lse + ((int64_t)batch * p.nsenses + l) * p.lse_stride + my_q_clamped);
+        };
+        auto adopt_q = [&]() {
+            wait_vmcnt<C::DMA_PER_STAGE>();   // everything older than the last step's DMA pieces has landed
+#pragma unroll
+            for (int s = 0; s < KD; ++s) {
+                asm volatile("" : "+v"(qn[s]));
+                qf[s] = (16 * s + 8 * hh < p.dk) ? qn[s] : u32x4{0u, 0u, 0u, 0u};
+            }
+            asm volatile("" : "+v"(lse_n));
+            lse2 = lse_n * kLog2e;
         };
 
         // S^T of the 32-key half kk of the tile in ring slot byte offset `stage`
@@ -401,18 +414,24 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
             slot = slot == 2 ? 0 : slot + 1;
             advance2();
         };
+        // (wider q.k products keep the plain per-sense load: 16 more live registers would spill there)
+        constexpr bool ASYNC_Q = KD <= 3;
+        if (ASYNC_Q && wave_has_rows) take_q(0);
         for (int l = 0; l < p.nsenses; ++l) {
-            if (wave_has_rows) take_q(l);
+            if (!ASYNC_Q && wave_has_rows) take_q(l);
+            const bool more = ASYNC_Q && wave_has_rows && l + 1 < p.nsenses;
             for (int kb = 0; kb < nkb_clean; ++kb) {
                 step_begin();
                 clean_step(slot * C::STAGE, l2, kb2, slot >= 1 ? slot - 1 : 2);
                 step_end();
             }
-            for (int kb = nkb_clean; kb < nkb; ++kb) {
+            for (int kb = nkb_clean; kb < nkb; ++kb) {   // (never empty: the diagonal tile is an edge tile)
                 step_begin();
+                if (more && kb == nkb - 1) request_q(l + 1);
                 edge_step(slot * C::STAGE, l, kb, l2, kb2, slot >= 1 ? slot - 1 : 2);
                 step_end();
             }
+            if (more) adopt_q();
         }
         wait_vmcnt<0>();   // the two re-fetched tiles: nothing may still be landing when the next job refills the ring
 
