@@ -120,6 +120,7 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
             if (idx < njobs) {
                 // all groups' heaviest tiles first (a group's tiles together, so that its C slab is re-read while it might
                 // still be cached, gained nothing: 1.32 / 1.34 ms against 1.29 / 1.28 ms at B = 64, same fetch traffic, r02_e)
+                // (sample-major order -- one sample's twelve jobs together -- fetches 4 % less and runs 2-3 % slower, r02_w)
                 const int slot = idx / groups;
                 const int grp = mix_queue_group(p.n_chunks, q, idx - slot * groups);
                 return grp * 256 + (p.n_qtiles - 1 - slot);
