@@ -34,8 +34,7 @@ inline bool dropout_args(float p, const uint64_t *rng_state, uint32_t &thr, floa
 
 // Measurement switches exist only in development builds (build_hip.py --variant NAME -- -DBP_DEV_BUILD):
 // the shipped library reads no environment variable.  BP_FLASH_IMPL=staged / BP_MIX_IMPL=staged force the
-// register-staged kernels for shapes the LDS-DMA ring kernels accept; BP_FLASH_PAIR=0 unpairs causal tiles;
-// BP_MIX_ORDER picks the sense-mix work order.
+// register-staged kernels for shapes the LDS-DMA ring kernels accept; BP_FLASH_PAIR=0 unpairs causal tiles.
 #ifdef BP_DEV_BUILD
 inline bool env_is(const char *name, const char *value) {
     const char *e = getenv(name);
