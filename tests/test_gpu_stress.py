@@ -66,3 +66,29 @@ def test_flash_fwd_repeats_bit_identically(cfg):
         assert torch.equal(out, first) and torch.equal(lse[..., :s], lse0), f'flash_fwd repetition {i} differs'
     torch.cuda.synchronize()
     del keep
+
+
+def test_persistent_mix_launches_on_several_streams():
+    """Persistent launches own one queue record each (a ring of 64 in the library): launches that overlap on different
+    streams must neither share tickets nor wait on each other."""
+    bp = _bp()
+    torch.manual_seed(7)
+    shapes = [(3, 512, 16, 48, 768), (2, 1024, 16, 48, 256), (4, 300, 4, 24, 104)]
+    data = []
+    for b, s, k, dk, d in shapes:
+        qk = (torch.randn(b, s, 2, k, dk, device=DEV) * 0.9).bfloat16()
+        c = torch.randn(b, s, k, d, device=DEV).bfloat16()
+        lse = bp.sense_lse(qk)
+        data.append((qk, c, lse, bp.sense_mix(qk, c, lse=lse).clone()))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in shapes]
+    for rnd in range(6):
+        outs = []
+        for st, (qk, c, lse, _) in zip(streams, data):
+            with torch.cuda.stream(st):
+                for _ in range(3):   # several launches in flight per stream
+                    out = bp.sense_mix(qk, c, lse=lse)
+                outs.append(out)
+        torch.cuda.synchronize()
+        for out, (_, _, _, want) in zip(outs, data):
+            assert torch.equal(out, want), f'round {rnd}: a concurrent launch produced a different result'
