@@ -95,12 +95,16 @@ def round_up(x, m):
     return (x + m - 1) // m * m
 
 
-def new_rng_state(device):
+def new_rng_state(device, generator=None):
     """Two fresh int64 words {seed, offset} ON THE DEVICE, drawn from torch's CUDA generator (so
-    `torch.manual_seed` makes dropout reproducible) -- the role of the at::Generator philox state the reference
-    hands its kernels (csrc/flash_attn/fmha_api.cpp:314-320).  Staying on the device keeps the call free of host
-    synchronisation and legal inside HIP-graph capture; save the tensor to regenerate the mask in backward."""
-    return torch.randint(-2 ** 63, 2 ** 63 - 1, (2,), dtype=torch.int64, device=device)
+    `torch.manual_seed` makes dropout reproducible) or from the caller's `generator` -- the role of the
+    at::Generator philox state the reference hands its kernels (csrc/flash_attn/fmha_api.cpp:314-320, `gen_`
+    argument).  Staying on the device keeps the call free of host synchronisation and legal inside HIP-graph
+    capture; save the tensor to regenerate the mask in backward.  A CPU generator is accepted too (its two words
+    are copied to the device: one small host-to-device transfer)."""
+    if generator is not None and torch.device(generator.device).type != torch.device(device).type:
+        return torch.randint(-2 ** 63, 2 ** 63 - 1, (2,), dtype=torch.int64, generator=generator).to(device)
+    return torch.randint(-2 ** 63, 2 ** 63 - 1, (2,), dtype=torch.int64, device=device, generator=generator)
 
 
 def _dropout_args(dropout_p, rng_state, device):

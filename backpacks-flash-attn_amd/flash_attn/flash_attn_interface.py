@@ -28,11 +28,10 @@ def _flash_attn_forward(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, 
     (b, h, max_seqlen_q, max_seqlen_k), only for fixed-length batches (testing aid, as upstream); with
     dropout, dropped entries carry a set sign bit (the reference encodes its mask in the sign of S_dmask too,
     tests/test_flash_attn.py:181-236).  `rng_state`: bp_hip.new_rng_state(); required when dropout_p > 0 and
-    the mask must be reproducible (backward)."""
-    if generator is not None:
-        raise RuntimeError('flash_attn (gfx950 build): pass rng_state (bp_hip.new_rng_state) instead of a generator')
+    the mask must be reproducible (backward).  `generator` (the reference's argument, :16,26): the state words are
+    drawn from it instead of torch's default CUDA generator."""
     if dropout_p > 0.0 and rng_state is None:
-        rng_state = bp_hip.new_rng_state(q.device)
+        rng_state = bp_hip.new_rng_state(q.device, generator)
     softmax_lse = bp_hip.flash_fwd(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q,
                                    max_seqlen_k, softmax_scale, causal, dropout_p, rng_state)
     S_dmask = None
@@ -49,7 +48,10 @@ def _flash_attn_backward(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens
                          max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale, causal, num_splits=0,
                          generator=None, rng_state=None):
     """Same contract as the reference's helper (:31-47): fills dq, dk, dv in place.  With dropout, `rng_state`
-    is the forward's (the reference restores the saved CUDA RNG state instead, :74-81)."""
+    is the forward's (the reference restores the saved CUDA RNG state instead, :74-81); a `generator` is accepted
+    for signature compatibility only -- the mask is a function of `rng_state`, nothing is drawn here."""
+    if dropout_p > 0.0 and rng_state is None:
+        raise RuntimeError('flash_attn (gfx950 build): backward with dropout needs the rng_state the forward used')
     bp_hip.flash_bwd(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seqlens_k,
                      max_seqlen_q, max_seqlen_k, softmax_scale, causal, dropout_p, rng_state)
     return dq, dk, dv

@@ -18,7 +18,7 @@ from flash_attn.modules.mha import MHA
 from flash_attn.modules.mlp import FusedDenseGeluDense, Mlp
 from flash_attn.ops.layer_norm import dropout_add_layer_norm
 from flash_attn.utils.pretrained import state_dict_from_pretrained
-from src.utils.hf_convert import gpt2_trunk_state_dict, remap_state_dict_gpt2
+from flash_attn.utils.hf_convert import gpt2_trunk_state_dict, remap_state_dict_gpt2
 
 
 def create_mixer_cls(config, layer_idx=None, process_group=None, device=None, dtype=None):

@@ -75,7 +75,7 @@ def main():
     # this repo's mirror, loaded by path: the package name `src` is the reference's here
     import importlib.util
     spec = importlib.util.spec_from_file_location(
-        'bp_hf_convert', os.path.join(ROOT, 'backpacks-flash-attn_amd', 'src', 'utils', 'hf_convert.py'))
+        'bp_hf_convert', os.path.join(ROOT, 'backpacks-flash-attn_amd', 'flash_attn', 'utils', 'hf_convert.py'))
     hf_convert = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(hf_convert)
 

@@ -387,20 +387,31 @@ def test_sense_mix_key_weight_hook(shape):
 # ---------------------------------------------------------------------------------------------
 # BASELINE config 5 shape (S = 4096, fp16): oracle on a subset of query rows (full key range)
 # ---------------------------------------------------------------------------------------------
+def _rows_softmax(scores, rows, s):
+    mask = torch.arange(s)[None, :] > rows[:, None]
+    return scores.masked_fill(mask[None], float('-inf'))
+
+
 def test_flash_fwd_seq4096_fp16_rows():
+    """2x-eager rule (tests/test_flash_attn.py:424-428) on a subset of query rows, full key range; one row carries a
+    score spike beyond the fp16 limit of the fast tile body (2^14, see tests/test_gpu_retry.py) deep in the sweep."""
     bp = _bp()
     torch.manual_seed(40)
     s, h, d = 4096, 12, 64
     qkv = torch.randn(1, s, 3, h, d).half()
+    qv = qkv[0, 4000, 0, 3].float()
+    qkv[0, 2500, 1, 3] = (qv * (14.0 / (qv.dot(qv).item() * d ** -0.5))).half()      # ~ +10 nats over the row maximum
     out, lse = run_flash_fixed(qkv.to(DEV), d ** -0.5, True)
     rows = torch.tensor([0, 1, 63, 64, 127, 128, 2047, 2048, 4000, 4095])
-    q, k, v = qkv[0, :, 0].float(), qkv[0, :, 1].float(), qkv[0, :, 2].float()
-    scores = torch.einsum('thd,shd->hts', q[rows], k) * d ** -0.5
-    mask = torch.arange(s)[None, :] > rows[:, None]
-    scores = scores.masked_fill(mask[None], float('-inf'))
-    want = torch.einsum('hts,shd->thd', torch.softmax(scores, -1), v)
-    assert (out[0, rows].float().cpu() - want).abs().max().item() < 4e-3
+    q16, k16, v16 = qkv[0, :, 0], qkv[0, :, 1], qkv[0, :, 2]
+    scores = _rows_softmax(torch.einsum('thd,shd->hts', q16[rows].float(), k16.float()) * d ** -0.5, rows, s)
+    want = torch.einsum('hts,shd->thd', torch.softmax(scores, -1), v16.float())
+    # the reference test's same-dtype eager: scale folded into k, every op in fp16
+    s16 = _rows_softmax(torch.einsum('thd,shd->hts', q16[rows], k16 * d ** -0.5), rows, s)
+    eager = torch.einsum('hts,shd->thd', torch.softmax(s16, -1), v16)
+    rel_check(out[0, rows], want, eager, 'flash S=4096 fp16 rows')
     assert (lse[0][:, rows].cpu() - torch.logsumexp(scores, -1)).abs().max().item() < 2e-3
+    assert scores[3, 8].max().item() - scores[3, 8, :64].max().item() > 9.8           # the spike is there
 
 
 def test_sense_mix_seq4096_fp16_rows():
@@ -411,12 +422,15 @@ def test_sense_mix_seq4096_fp16_rows():
     c = torch.randn(1, s, k, d).half()
     out = bp.sense_mix(qk.to(DEV), c.to(DEV))
     rows = torch.tensor([0, 31, 32, 255, 256, 1023, 1024, 3000, 4095])
-    q, kk = qk[0, :, 0].float(), qk[0, :, 1].float()
-    scores = torch.einsum('tld,sld->lts', q[rows], kk) * dk ** -0.5
-    mask = torch.arange(s)[None, :] > rows[:, None]
-    alpha = torch.softmax(scores.masked_fill(mask[None], float('-inf')), -1)         # (k, rows, S)
-    want = torch.einsum('lts,sld->td', alpha, c[0].float())
-    assert (out[0, rows].float().cpu() - want).abs().max().item() < 2e-2
+    q16, k16 = qk[0, :, 0], qk[0, :, 1]
+    scores = _rows_softmax(torch.einsum('tld,sld->lts', q16[rows].float(), k16.float()) * dk ** -0.5, rows, s)
+    want = torch.einsum('lts,sld->td', torch.softmax(scores, -1), c[0].float())
+    # same-dtype eager in the reference's op order (backpack.py:116-122,313): fp16 scores / softmax, one fp16
+    # (rows x S) @ (S x d) product per sense, summed over the senses in fp16
+    s16 = _rows_softmax(torch.einsum('tld,sld->lts', q16[rows], k16) / math.sqrt(dk), rows, s)
+    a16 = torch.softmax(s16, -1)
+    eager = torch.stack([a16[l] @ c[0, :, l] for l in range(k)]).sum(0)
+    rel_check(out[0, rows], want, eager, 'mix S=4096 fp16 rows', atol=2e-3)
 
 
 # ---------------------------------------------------------------------------------------------

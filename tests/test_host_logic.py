@@ -205,6 +205,34 @@ def test_generation_matches_the_reference_token_for_token():
     assert tuple(model.sample(prompt, max_length=12).shape) == tuple(g8['sample_12_shape'])
 
 
+def test_hf_gpt2_state_dict_of_the_installed_transformers_loads():
+    """State dicts of the installed `transformers` (no `attn.bias` / `attn.masked_bias` buffers any more: they are
+    non-persistent there) go through `from_pretrained` unmodified, for GPT2Model- and GPT2LMHeadModel-style keys,
+    and reproduce transformers' own logits."""
+    from transformers import GPT2Config, GPT2LMHeadModel
+    from flash_attn.models.gpt import GPTLMHeadModel
+    import flash_attn.utils.hf_convert as conv
+    import src.utils.hf_convert as conv_src
+    assert conv_src.remap_state_dict_gpt2 is conv.remap_state_dict_gpt2      # one implementation, two import paths
+    kw = dict(n_embd=32, n_head=2, n_layer=2, n_positions=16, resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0)
+    torch.manual_seed(0)
+    hf_model = GPT2LMHeadModel(GPT2Config(vocab_size=50, **kw)).eval()
+    sd = hf_model.state_dict()
+    ids = torch.randint(0, 50, (2, 16))
+    with torch.no_grad():
+        want = hf_model(ids).logits
+    for state in (sd, hf_model.transformer.state_dict()):
+        cfg = GPT2Config(vocab_size=50, **kw)
+        cfg.pad_vocab_size_multiple = 8
+        model = GPTLMHeadModel.from_pretrained('unused', cfg, state_dict=dict(state)).eval()
+        with torch.no_grad():
+            got = model(ids).logits[..., :50]
+        assert (got - want).abs().max().item() < 1e-4
+    bcfg = BackpackConfig(vocab_size=50, num_content_vectors=4, pad_vocab_size_multiple=8, **kw)
+    bp_model = BackpackLMHeadModel.from_pretrained('unused', bcfg, state_dict=dict(sd))
+    assert torch.equal(bp_model.lm_head.weight[:50], sd['transformer.wte.weight'])
+
+
 def test_hf_gpt2_remap_matches_the_reference_and_transformers():
     """G7: `remap_state_dict_gpt2` / `remap_state_dict_flash` against the outputs of the reference's functions
     on the same tiny HF state dict (bit-exact: renames, transposes, zero padding), and `from_pretrained` end to
