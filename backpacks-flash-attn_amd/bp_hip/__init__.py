@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('BP_HIP_LIB') or os.path.join(_HERE, 'libbackpack_hip.so')  # env: A/B builds only
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 
@@ -31,9 +31,9 @@ SIGNATURES = {
     'bp_attn_probs_dropout': (_i32, [_ptr] * 4 + [_i32] * 5 + [_i64] * 10 + [_f32, _i32, _i32, _f32, _ptr, _ptr]),
     'bp_sense_lse': (_i32, [_ptr] * 2 + [_i32] * 4 + [_i64] * 4 + [_f32, _i32, _ptr]),
     'bp_sense_alpha': (_i32, [_ptr] * 3 + [_i32] * 5 + [_i64] * 4 + [_f32, _i32, _ptr]),
-    'bp_sense_mix': (_i32, [_ptr] * 4 + [_i32] * 6 + [_i64] * 9 + [_f32, _i32, _ptr]),
-    'bp_sense_mix_weighted': (_i32, [_ptr] * 5 + [_i32] * 6 + [_i64] * 11 + [_f32, _i32, _ptr]),
-    'bp_sense_mix_dc': (_i32, [_ptr] * 4 + [_i32] * 5 + [_i64] * 9 + [_f32, _i32, _ptr]),
+    'bp_sense_mix': (_i32, [_ptr] * 4 + [_i32] * 6 + [_i64] * 9 + [_f32, _i32, _ptr, _ptr]),
+    'bp_sense_mix_weighted': (_i32, [_ptr] * 5 + [_i32] * 6 + [_i64] * 11 + [_f32, _i32, _ptr, _ptr]),
+    'bp_sense_mix_dc': (_i32, [_ptr] * 4 + [_i32] * 5 + [_i64] * 9 + [_f32, _i32, _ptr, _ptr]),
     'bp_sense_dq_dk': (_i32, [_ptr] * 6 + [_i32] * 5 + [_i64] * 11 + [_f32, _i32, _ptr]),
     'bp_add_layer_norm': (_i32, [_ptr] * 6 + [_i64, _i32, _f32] + [_i32] * 4 + [_ptr]),
     'bp_dropout_add_layer_norm': (_i32, [_ptr] * 7 + [_i64, _i32, _f32] + [_i32] * 5 + [_f32, _ptr, _ptr]),
@@ -42,6 +42,10 @@ SIGNATURES = {
     'bp_add_layer_norm_bwd': (_i32, [_ptr] * 9 + [_i64, _i32, _f32, _i32, _i32, _i32, _ptr]),
     'bp_xentropy_fwd': (_i32, [_ptr] * 4 + [_i64, _i32, _i64, _f32, _i32, _i32, _ptr]),
     'bp_xentropy_bwd': (_i32, [_ptr] * 5 + [_i64, _i32, _i64, _i64, _f32, _i32, _i32, _ptr]),
+    'bp_bias_grad_ws_floats': (_i64, [_i64, _i32]),
+    'bp_bias_gelu_fwd': (_i32, [_ptr] * 4 + [_i64, _i32, _i32, _ptr]),
+    'bp_bias_gelu_bwd': (_i32, [_ptr] * 5 + [_i64, _i32, _i32, _i32, _ptr]),
+    'bp_column_sum': (_i32, [_ptr] * 3 + [_i64, _i32, _i32, _i32, _ptr]),
 }
 
 
@@ -270,6 +274,13 @@ def attn_probs(q, k, lse, softmax_scale, causal, dropout_p=0.0, rng_state=None):
     return probs
 
 
+def _queue_ws(device):
+    """The 64-byte ticket record of ONE persistent sense-mix launch (include/bp_hip.h: queue_ws).  A fresh tensor per
+    call from torch's stream-ordered caching allocator: while a HIP graph is being captured it comes from the graph's
+    private pool, so the graph owns the record it replays and no eager launch can ever share it."""
+    return torch.empty(16, dtype=torch.int32, device=device)
+
+
 def _check_qk(qk):
     _require_cuda(qk)
     if qk.dim() != 5 or qk.shape[2] != 2 or qk.stride(-1) != 1:
@@ -366,7 +377,7 @@ def sense_mix(qk, content, softmax_scale=None, out=None, lse=None, key_weight=No
             qk.stride(0), qk.stride(1), qk.stride(2), qk.stride(3),
             content.stride(0), content.stride(1), content.stride(2),
             kw.stride(0) if kw is not None else 0, kw.stride(1) if kw is not None else 0,
-            out.stride(0), out.stride(1), float(scale), _dtype_code(qk), _stream())
+            out.stride(0), out.stride(1), float(scale), _dtype_code(qk), _queue_ws(qk.device).data_ptr(), _stream())
     _check(code, 'bp_sense_mix_weighted')
     return out
 
@@ -466,7 +477,7 @@ def sense_mix_dc(qk, dout, lse, softmax_scale, like):
             qk.data_ptr(), dout.data_ptr(), lse.data_ptr(), dcontent.data_ptr(), b, s, k, dk, like.shape[-1],
             qk.stride(0), qk.stride(1), qk.stride(2), qk.stride(3), dout.stride(0), dout.stride(1),
             dcontent.stride(0), dcontent.stride(1), dcontent.stride(2), float(softmax_scale), _dtype_code(qk),
-            _stream())
+            _queue_ws(qk.device).data_ptr(), _stream())
     _check(code, 'bp_sense_mix_dc')
     return dcontent
 
@@ -683,6 +694,80 @@ def xentropy_bwd(grad_losses, logits, lse, labels, smoothing=0.0, inplace=False,
                                      float(smoothing), int(total_classes), _xent_dtype(logits), _stream())
     _check(code, 'bp_xentropy_bwd')
     return grad
+
+
+def bias_gelu_supported(x):
+    """Shapes / dtypes bp_bias_gelu_* and bp_column_sum take (callers use the torch expressions otherwise)."""
+    return x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.shape[-1] % 8 == 0 and x.numel() > 0
+
+
+def _rows_cols(x):
+    if x.stride(-1) != 1 or not x.is_contiguous():
+        raise RuntimeError('bp_hip: bias/GELU kernels take contiguous (rows, cols) tensors')
+    return x.numel() // x.shape[-1], x.shape[-1]
+
+
+def bias_gelu_fwd(x, bias=None, save_pre=False, out=None):
+    """y = gelu_tanh(x + bias) for a contiguous 16-bit (..., cols) tensor; returns (y, pre) where pre = x + bias
+    (16-bit) when save_pre -- without a bias, pre IS x.  `out` may be x itself (in place).  C ABI bp_bias_gelu_fwd:
+    the elementwise half of the reference's `linear_gelu_forward` (flash_attn/ops/fused_dense.py:220)."""
+    _require_cuda(x, bias, out)
+    rows, cols = _rows_cols(x)
+    if bias is not None and (bias.shape != (cols,) or bias.dtype != x.dtype or not bias.is_contiguous()):
+        raise RuntimeError('bp_hip.bias_gelu_fwd: bias must be a contiguous (cols,) tensor of x\'s dtype')
+    y = torch.empty_like(x) if out is None else out
+    pre = torch.empty_like(x) if (save_pre and bias is not None) else None
+    with torch.cuda.device(x.device):
+        code = lib().bp_bias_gelu_fwd(x.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                      pre.data_ptr() if pre is not None else None, y.data_ptr(), rows, cols,
+                                      _dtype_code(x), _stream())
+    _check(code, 'bp_bias_gelu_fwd')
+    return y, (pre if pre is not None else (x if save_pre else None))
+
+
+def _bias_grad_ws(rows, cols, device):
+    return torch.empty(int(lib().bp_bias_grad_ws_floats(rows, cols)), dtype=torch.float32, device=device)
+
+
+def bias_gelu_bwd(grad, pre, bias_grad_dtype=None, inplace=False):
+    """(dpre, dbias): dpre = grad * gelu_tanh'(pre) in grad's dtype (written over `grad` when inplace) and, when
+    bias_grad_dtype is given (fp32 or grad's dtype), dbias = column sums of dpre -- one pass over the two tensors, the
+    reference's `bias_gelu_linear_dgrad_bgrad` epilogue (flash_attn/ops/fused_dense.py:290) minus the GEMM."""
+    _require_cuda(grad, pre)
+    rows, cols = _rows_cols(grad)
+    if pre.shape != grad.shape or pre.dtype != grad.dtype or not pre.is_contiguous():
+        raise RuntimeError('bp_hip.bias_gelu_bwd: pre must match grad')
+    dpre = grad if inplace else torch.empty_like(grad)
+    dbias = ws = None
+    if bias_grad_dtype is not None:
+        if bias_grad_dtype not in (torch.float32, grad.dtype):
+            raise RuntimeError('bp_hip.bias_gelu_bwd: bias gradient dtype must be fp32 or grad\'s dtype')
+        dbias = torch.empty(cols, dtype=bias_grad_dtype, device=grad.device)
+        ws = _bias_grad_ws(rows, cols, grad.device)
+    with torch.cuda.device(grad.device):
+        code = lib().bp_bias_gelu_bwd(grad.data_ptr(), pre.data_ptr(), dpre.data_ptr(),
+                                      dbias.data_ptr() if dbias is not None else None,
+                                      ws.data_ptr() if ws is not None else None, rows, cols, _dtype_code(grad),
+                                      int(bias_grad_dtype == torch.float32), _stream())
+    _check(code, 'bp_bias_gelu_bwd')
+    return dpre, dbias
+
+
+def column_sum(grad, out_dtype=None):
+    """dbias (cols,) = sum over the rows of a contiguous 16-bit (..., cols) tensor, deterministic (C ABI
+    bp_column_sum): the bias-gradient half of the reference's `linear_bias_wgrad` (fused_dense.py:66,281)."""
+    _require_cuda(grad)
+    rows, cols = _rows_cols(grad)
+    out_dtype = out_dtype or grad.dtype
+    if out_dtype not in (torch.float32, grad.dtype):
+        raise RuntimeError('bp_hip.column_sum: output dtype must be fp32 or grad\'s dtype')
+    dbias = torch.empty(cols, dtype=out_dtype, device=grad.device)
+    ws = _bias_grad_ws(rows, cols, grad.device)
+    with torch.cuda.device(grad.device):
+        code = lib().bp_column_sum(grad.data_ptr(), dbias.data_ptr(), ws.data_ptr(), rows, cols, _dtype_code(grad),
+                                   int(out_dtype == torch.float32), _stream())
+    _check(code, 'bp_column_sum')
+    return dbias
 
 
 class GraphedForward:

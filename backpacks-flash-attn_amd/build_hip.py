@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OUT_DIR = os.path.join(CSRC, 'build')
 LIB = os.path.join(HERE, 'bp_hip', 'libbackpack_hip.so')
 SOURCES = ['flash_fwd.hip', 'flash_fwd_dma.hip', 'flash_bwd.hip', 'sense_mix.hip', 'sense_mix_dma.hip', 'sense_mix_bwd.hip', 'attn_probs.hip',
-           'add_layer_norm.hip', 'xentropy.hip', 'softmax_bwd.hip', 'bp_api.hip']
+           'add_layer_norm.hip', 'xentropy.hip', 'softmax_bwd.hip', 'bias_gelu.hip', 'bp_api.hip']
 HEADERS = ['bp_common.h', 'bp_dma.h', 'bp_kernels.h', 'bp_philox.h', os.path.join('..', '..', 'include', 'bp_hip.h')]
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has one unified file); without it
 # hipcc parks them in AGPRs and copies 64+ registers per tile around the softmax (measured +4..10 %).

@@ -1,0 +1,209 @@
+// Elementwise halves of the reference's fused dense layers for gfx950 (second half):
+// what its cuBLASLt epilogues do around the GEMMs of `FusedDenseGeluDenseFunc`
+// (flash_attn/ops/fused_dense.py:175-330; csrc/fused_dense_lib/fused_dense.cpp:195-197 `linear_gelu_forward`,
+// `bias_gelu_linear_dgrad_bgrad`, `linear_bias_wgrad`), as stand-alone HBM-bound passes -- the GEMMs themselves stay
+// on the BLAS library:
+//
+//   bias_gelu_fwd   y = gelu_tanh(x + bias)              and, when asked, pre = x + bias (what backward needs)
+//   bias_gelu_bwd   dpre = g * gelu_tanh'(pre)           and  dbias[c] = sum_r dpre[r, c]   in the SAME pass
+//   column_sum      dbias[c] = sum_r g[r, c]             (bias gradient of a plain dense layer, `linear_bias_wgrad`)
+//
+// gelu_tanh is GPT-2's `gelu_new`: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))), the approximation the reference's
+// epilogue and `F.gelu(approximate='tanh')` use.  tanh(u) = 1 - 2 / (1 + e^(2u)) through v_exp_f32 / v_rcp_f32.
+//
+// Layout: rows x cols 16-bit, unit column stride, cols % 8 == 0; a thread owns 8 consecutive columns (one 16-byte
+// access per row), a 128-thread workgroup 1024 columns.  The column sums are deterministic, two stages, no atomics:
+// workgroup (chunk, slice) walks rows slice, slice + n_slices, ... with its 8 sums in registers and writes one partial
+// row; the second kernel adds the partial rows in a fixed order.  Bytes per element: forward 2 read + 2 (or 4)
+// written, backward 4 read + 2 written, column sum 2 read.
+#include "bp_common.h"
+#include "bp_kernels.h"
+
+namespace bp {
+
+namespace {
+
+constexpr float kGeluA = 0.7978845608028654f;   // sqrt(2 / pi)
+constexpr float kGeluB = 0.044715f;
+
+// tanh of the GELU argument, from x
+BP_DEV float gelu_tanh_arg(float x) {
+    const float u = kGeluA * x * fmaf(kGeluB * x, x, 1.f);
+    // tanh(u) = 1 - 2 / (1 + exp(2u)); exp2 overflow -> inf -> rcp 0 -> 1, underflow -> 0 -> -1: no clamp needed
+    const float e = fast_exp2(u * (2.f * kLog2e));
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + e);
+}
+BP_DEV float gelu_fwd(float x) { return 0.5f * x * (1.f + gelu_tanh_arg(x)); }
+BP_DEV float gelu_grad(float x) {
+    const float t = gelu_tanh_arg(x);
+    const float du = kGeluA * fmaf(3.f * kGeluB * x, x, 1.f);
+    return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * du;
+}
+
+template <class ET> BP_DEV void unpack8(const u32x4 w, float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t x = w[i];   // by-value copy (bp_common.h, as_f32)
+        v[2 * i] = Elem<ET>::lo_f32(x);
+        v[2 * i + 1] = Elem<ET>::hi_f32(x);
+    }
+}
+template <class ET> BP_DEV u32x4 pack8(const float (&v)[8]) {
+    return u32x4{Elem<ET>::pack2(v[0], v[1]), Elem<ET>::pack2(v[2], v[3]), Elem<ET>::pack2(v[4], v[5]),
+                 Elem<ET>::pack2(v[6], v[7])};
+}
+
+}  // namespace
+
+// ---- forward: flat over 16-byte chunks, grid-stride ------------------------------------------------------------
+template <class ET, bool HAS_BIAS, bool SAVE_PRE>
+__global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(const BiasGeluParams p) {
+    const int64_t nchunks = p.rows * (p.cols / 8);
+    const int cpr = p.cols / 8;   // chunks per row
+    const u32x4 *x = static_cast<const u32x4 *>(p.x);
+    u32x4 *y = static_cast<u32x4 *>(p.y);
+    u32x4 *pre = static_cast<u32x4 *>(p.pre);
+    const u32x4 *bias = static_cast<const u32x4 *>(p.bias);
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += stride) {
+        float v[8];
+        unpack8<ET>(x[i], v);
+        if (HAS_BIAS) {
+            float b[8];
+            unpack8<ET>(bias[i % cpr], b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += b[j];
+            if (SAVE_PRE) {
+                // the saved pre-activation is the ROUNDED sum and the GELU is taken of that rounded value, so that the
+                // backward differentiates exactly the function the forward evaluated
+                const u32x4 w = pack8<ET>(v);
+                pre[i] = w;
+                unpack8<ET>(w, v);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = gelu_fwd(v[j]);
+        y[i] = pack8<ET>(v);
+    }
+}
+
+// ---- backward / column sums --------------------------------------------------------------------------------------
+// grid (column chunks of 1024, slices); GELU = false: plain column sums of g (no pre, no dpre)
+template <class ET, bool GELU>
+__global__ __launch_bounds__(128) void bias_gelu_bwd_kernel(const BiasGeluParams p) {
+    const int col = (blockIdx.x * 128 + threadIdx.x) * 8;
+    if (col >= p.cols) return;
+    const int64_t cpr = p.cols / 8;
+    const u32x4 *g = static_cast<const u32x4 *>(p.x) + col / 8;
+    const u32x4 *pre = static_cast<const u32x4 *>(p.pre) + col / 8;
+    u32x4 *dpre = static_cast<u32x4 *>(p.y) + col / 8;
+    float sum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum[j] = 0.f;
+    const int nsl = gridDim.y;
+    int64_t r = blockIdx.y;
+    // two rows per trip: both loads are in flight before the first exp
+    for (; r + nsl < p.rows; r += 2 * nsl) {
+        const u32x4 g0 = g[r * cpr], g1 = g[(r + nsl) * cpr];
+        float a[8], b[8];
+        unpack8<ET>(g0, a);
+        unpack8<ET>(g1, b);
+        if (GELU) {
+            const u32x4 x0 = pre[r * cpr], x1 = pre[(r + nsl) * cpr];
+            float xa[8], xb[8];
+            unpack8<ET>(x0, xa);
+            unpack8<ET>(x1, xb);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a[j] *= gelu_grad(xa[j]); b[j] *= gelu_grad(xb[j]); }
+            const u32x4 w0 = pack8<ET>(a), w1 = pack8<ET>(b);
+            dpre[r * cpr] = w0;
+            dpre[(r + nsl) * cpr] = w1;
+            unpack8<ET>(w0, a);   // dbias sums the rounded values the weight-gradient GEMM will see
+            unpack8<ET>(w1, b);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum[j] += a[j] + b[j];
+    }
+    if (r < p.rows) {
+        float a[8];
+        unpack8<ET>(g[r * cpr], a);
+        if (GELU) {
+            float xa[8];
+            unpack8<ET>(pre[r * cpr], xa);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] *= gelu_grad(xa[j]);
+            const u32x4 w0 = pack8<ET>(a);
+            dpre[r * cpr] = w0;
+            unpack8<ET>(w0, a);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum[j] += a[j];
+    }
+    if (p.ws != nullptr) {
+        float *out = p.ws + (int64_t)blockIdx.y * p.cols + col;
+        *reinterpret_cast<f32x4 *>(out) = f32x4{sum[0], sum[1], sum[2], sum[3]};
+        *reinterpret_cast<f32x4 *>(out + 4) = f32x4{sum[4], sum[5], sum[6], sum[7]};
+    }
+}
+
+// second stage: dbias[c] = sum over the partial rows, fixed order; one thread per column, 4 independent chains
+template <class ET>
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const BiasGeluParams p, int nsl) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= p.cols) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = 0;
+    for (; i + 3 < nsl; i += 4) {
+        s0 += p.ws[(int64_t)i * p.cols + c];
+        s1 += p.ws[(int64_t)(i + 1) * p.cols + c];
+        s2 += p.ws[(int64_t)(i + 2) * p.cols + c];
+        s3 += p.ws[(int64_t)(i + 3) * p.cols + c];
+    }
+    for (; i < nsl; ++i) s0 += p.ws[(int64_t)i * p.cols + c];
+    const float s = (s0 + s1) + (s2 + s3);
+    if (p.dbias_f32) static_cast<float *>(p.dbias)[c] = s;
+    else static_cast<uint16_t *>(p.dbias)[c] = Elem<ET>::from_float(s);
+}
+
+template <class ET>
+static hipError_t fwd_et(const BiasGeluParams &p, hipStream_t stream) {
+    const int64_t nchunks = p.rows * (p.cols / 8);
+    int64_t wgs = (nchunks + 255) / 256;
+    if (wgs > 8192) wgs = 8192;   // 32 resident waves per CU x 256 CUs, then grid-stride
+    dim3 g((unsigned)wgs), t(256);
+    if (p.bias == nullptr) hipLaunchKernelGGL((bias_gelu_fwd_kernel<ET, false, false>), g, t, 0, stream, p);
+    else if (p.pre != nullptr) hipLaunchKernelGGL((bias_gelu_fwd_kernel<ET, true, true>), g, t, 0, stream, p);
+    else hipLaunchKernelGGL((bias_gelu_fwd_kernel<ET, true, false>), g, t, 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_bias_gelu_fwd(const BiasGeluParams &p, int dtype, hipStream_t stream) {
+    return dtype == 1 ? fwd_et<BF16>(p, stream) : fwd_et<F16>(p, stream);
+}
+
+int bias_gelu_bwd_slices(int64_t rows, int cols) {
+    const int chunks = (cols + 1023) / 1024;
+    int64_t nsl = (4096 + chunks - 1) / chunks;   // ~4096 workgroups of 2 waves: 32 waves per CU
+    if (nsl > kBiasGeluMaxSlices) nsl = kBiasGeluMaxSlices;
+    if (nsl > (rows + 1) / 2) nsl = (rows + 1) / 2;   // at least two rows per slice where there are that many
+    return (int)(nsl < 1 ? 1 : nsl);
+}
+
+template <class ET>
+static hipError_t bwd_et(const BiasGeluParams &p, bool gelu, hipStream_t stream) {
+    const int chunks = (p.cols + 1023) / 1024;
+    const int nsl = bias_gelu_bwd_slices(p.rows, p.cols);
+    dim3 g(chunks, nsl), t(128);
+    if (gelu) hipLaunchKernelGGL((bias_gelu_bwd_kernel<ET, true>), g, t, 0, stream, p);
+    else hipLaunchKernelGGL((bias_gelu_bwd_kernel<ET, false>), g, t, 0, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || p.dbias == nullptr) return e;
+    hipLaunchKernelGGL((colsum_finish_kernel<ET>), dim3((p.cols + 255) / 256), dim3(256), 0, stream, p, nsl);
+    return hipGetLastError();
+}
+
+hipError_t launch_bias_gelu_bwd(const BiasGeluParams &p, int dtype, bool gelu, hipStream_t stream) {
+    return dtype == 1 ? bwd_et<BF16>(p, gelu, stream) : bwd_et<F16>(p, gelu, stream);
+}
+
+}  // namespace bp

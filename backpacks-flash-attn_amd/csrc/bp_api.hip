@@ -258,11 +258,11 @@ int bp_sense_mix(const void *qk, const void *content, void *out, float *lse_ws, 
                  int64_t qk_sense_stride,
                  int64_t c_batch_stride, int64_t c_row_stride, int64_t c_sense_stride,
                  int64_t o_batch_stride, int64_t o_row_stride,
-                 float softmax_scale, int dtype, bp_stream_t stream) {
+                 float softmax_scale, int dtype, void *queue_ws, bp_stream_t stream) {
     return bp_sense_mix_weighted(qk, content, nullptr, out, lse_ws, lse_ready, batch, seqlen, nsenses, d_k, d_out,
                                  qk_batch_stride, qk_row_stride, qk_two_stride, qk_sense_stride, c_batch_stride,
                                  c_row_stride, c_sense_stride, 0, 0, o_batch_stride, o_row_stride, softmax_scale,
-                                 dtype, stream);
+                                 dtype, queue_ws, stream);
 }
 
 int bp_sense_mix_weighted(const void *qk, const void *content, const float *key_weight, void *out,
@@ -273,9 +273,10 @@ int bp_sense_mix_weighted(const void *qk, const void *content, const float *key_
                           int64_t c_batch_stride, int64_t c_row_stride, int64_t c_sense_stride,
                           int64_t kw_batch_stride, int64_t kw_sense_stride,
                           int64_t o_batch_stride, int64_t o_row_stride,
-                          float softmax_scale, int dtype, bp_stream_t stream) {
+                          float softmax_scale, int dtype, void *queue_ws, bp_stream_t stream) {
     if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
     if (d_k < 1 || d_k > 128) return BP_ERR_HEAD_DIM;
+    if (queue_ws != nullptr && !aligned16(queue_ws)) return BP_ERR_SHAPE;
     if (d_out < 1) return BP_ERR_DOUT;
     if (batch <= 0 || nsenses <= 0 || seqlen <= 0) return BP_ERR_SHAPE;
     if (qk == nullptr || content == nullptr || out == nullptr || lse_ws == nullptr) return BP_ERR_SHAPE;
@@ -299,6 +300,7 @@ int bp_sense_mix_weighted(const void *qk, const void *content, const float *key_
     p.n_qtiles = (seqlen + 255) / 256;
     p.n_chunks = (d_out + 255) / 256;
     p.scale_log2e = softmax_scale * bp::kLog2e;
+    p.queues = static_cast<bp::MixQueues *>(queue_ws);
     const bool vec_qk = (d_k % 8 == 0) && aligned16(p.q) && aligned16(p.k) && mult8(qk_batch_stride) &&
                         mult8(qk_row_stride) && mult8(qk_sense_stride);
     const bool vec_c = (d_out % 8 == 0) && aligned16(content) && aligned16(out) && mult8(c_batch_stride) &&
@@ -315,9 +317,10 @@ int bp_sense_mix_dc(const void *qk, const void *dout, const float *lse, void *dc
                     int64_t qk_batch_stride, int64_t qk_row_stride, int64_t qk_two_stride, int64_t qk_sense_stride,
                     int64_t do_batch_stride, int64_t do_row_stride,
                     int64_t c_batch_stride, int64_t c_row_stride, int64_t c_sense_stride,
-                    float softmax_scale, int dtype, bp_stream_t stream) {
+                    float softmax_scale, int dtype, void *queue_ws, bp_stream_t stream) {
     if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
     if (d_k < 8 || d_k > 128 || d_k % 8 != 0) return BP_ERR_HEAD_DIM;
+    if (queue_ws != nullptr && !aligned16(queue_ws)) return BP_ERR_SHAPE;
     if (d_out < 8 || d_out % 8 != 0) return BP_ERR_DOUT;
     if (batch <= 0 || nsenses <= 0 || seqlen <= 0 || seqlen > 65536) return BP_ERR_SHAPE;
     if (qk == nullptr || dout == nullptr || lse == nullptr || dcontent == nullptr) return BP_ERR_SHAPE;
@@ -337,6 +340,7 @@ int bp_sense_mix_dc(const void *qk, const void *dout, const float *lse, void *dc
     p.n_ktiles = (seqlen + 255) / 256;
     p.n_chunks = (d_out + 255) / 256;
     p.scale_log2e = softmax_scale * bp::kLog2e;
+    p.queues = static_cast<bp::MixQueues *>(queue_ws);
     hipError_t e = bp::launch_sense_mix_dc(p, dtype, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
 }
@@ -519,6 +523,55 @@ int bp_dropout_add_layer_norm_bwd(const void *dz, const void *dx_in, const void 
     if (!dropout_args(p_dropout, rng_state, p.drop_thr, p.drop_scale)) return BP_ERR_DROPOUT;
     hipError_t e = bp::launch_add_layer_norm_bwd(p, dtype, static_cast<hipStream_t>(stream));
     if (e == hipErrorNotSupported) return BP_ERR_SHAPE;
+    return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
+}
+
+int64_t bp_bias_grad_ws_floats(int64_t rows, int cols) {
+    if (rows <= 0 || cols <= 0) return 0;
+    return (int64_t)bp::bias_gelu_bwd_slices(rows, cols) * cols;
+}
+
+int bp_bias_gelu_fwd(const void *x, const void *bias, void *pre_out, void *y, int64_t rows, int cols, int dtype,
+                     bp_stream_t stream) {
+    if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
+    if (rows <= 0 || cols <= 0 || cols % 8 != 0) return BP_ERR_SHAPE;
+    if (x == nullptr || y == nullptr || !aligned16(x) || !aligned16(y)) return BP_ERR_SHAPE;
+    if ((bias != nullptr && !aligned16(bias)) || (pre_out != nullptr && !aligned16(pre_out))) return BP_ERR_SHAPE;
+    if (pre_out != nullptr && bias == nullptr) return BP_ERR_SHAPE;   // without a bias the pre-activation IS x
+    bp::BiasGeluParams p{};
+    p.x = x; p.bias = bias; p.pre = pre_out; p.y = y; p.rows = rows; p.cols = cols;
+    hipError_t e = bp::launch_bias_gelu_fwd(p, dtype, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
+}
+
+static int bias_grad_common(const void *grad, void *dbias, float *ws, int64_t rows, int cols, int dtype) {
+    if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
+    if (rows <= 0 || cols <= 0 || cols % 8 != 0) return BP_ERR_SHAPE;
+    if (grad == nullptr || !aligned16(grad)) return BP_ERR_SHAPE;
+    if (dbias != nullptr && (ws == nullptr || !aligned16(ws))) return BP_ERR_SHAPE;
+    return BP_OK;
+}
+
+int bp_bias_gelu_bwd(const void *grad, const void *pre, void *dpre, void *dbias, float *ws, int64_t rows, int cols,
+                     int dtype, int dbias_is_f32, bp_stream_t stream) {
+    const int rc = bias_grad_common(grad, dbias, ws, rows, cols, dtype);
+    if (rc != BP_OK) return rc;
+    if (pre == nullptr || dpre == nullptr || !aligned16(pre) || !aligned16(dpre)) return BP_ERR_SHAPE;
+    bp::BiasGeluParams p{};
+    p.x = grad; p.pre = const_cast<void *>(pre); p.y = dpre; p.dbias = dbias; p.ws = dbias != nullptr ? ws : nullptr;
+    p.rows = rows; p.cols = cols; p.dbias_f32 = dbias_is_f32 ? 1 : 0;
+    hipError_t e = bp::launch_bias_gelu_bwd(p, dtype, true, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
+}
+
+int bp_column_sum(const void *grad, void *dbias, float *ws, int64_t rows, int cols, int dtype, int dbias_is_f32,
+                  bp_stream_t stream) {
+    const int rc = bias_grad_common(grad, dbias, ws, rows, cols, dtype);
+    if (rc != BP_OK) return rc;
+    if (dbias == nullptr) return BP_ERR_SHAPE;
+    bp::BiasGeluParams p{};
+    p.x = grad; p.dbias = dbias; p.ws = ws; p.rows = rows; p.cols = cols; p.dbias_f32 = dbias_is_f32 ? 1 : 0;
+    hipError_t e = bp::launch_bias_gelu_bwd(p, dtype, false, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
 }
 

@@ -61,12 +61,13 @@ struct ProbsParams {
     uint32_t drop_thr;
 };
 
-// job queues of the persistent sense-mix launch (sense_mix_dma.hip): one ticket per XCD + an exit counter
+// job queues of the persistent sense-mix launches (sense_mix_dma.hip, sense_mix_bwd.hip): one ticket per XCD.
+// 64 bytes, zeroed in front of every launch (arm_mix_queues)
 struct MixQueues {
     unsigned int ticket[8];
-    unsigned int done;
-    unsigned int pad[7];
+    unsigned int pad[8];
 };
+hipError_t arm_mix_queues(MixQueues *&queues, hipStream_t stream);   // NULL -> a record of the library's ring
 
 struct MixParams {
     const void *q, *k;        // q_l[t] = q + b*qk_bs + t*qk_rs + l*qk_ss ; k likewise
@@ -83,7 +84,7 @@ struct MixParams {
     int n_qtiles;             // ceil(s / 256)
     int n_chunks;             // ceil(dout / 256)
     float scale_log2e;
-    MixQueues *queues;        // filled in by launch_sense_mix_dma
+    MixQueues *queues;        // caller's record (queue_ws) or NULL; armed by launch_sense_mix_dma
 };
 
 // backward of the sense combination (sense_mix_bwd.hip)
@@ -100,7 +101,7 @@ struct MixBwdParams {
     int n_ktiles;             // ceil(s / 256)
     int n_chunks;             // ceil(dout_cols / 256)
     float scale_log2e;
-    MixQueues *queues;        // filled in by launch_sense_mix_dc
+    MixQueues *queues;        // caller's record (queue_ws) or NULL; armed by launch_sense_mix_dc
 };
 hipError_t launch_sense_mix_dc(const MixBwdParams &p, int dtype, hipStream_t stream);
 
@@ -184,6 +185,22 @@ struct LnBwdParams {
     float drop_scale;
 };
 hipError_t launch_add_layer_norm_bwd(const LnBwdParams &p, int dtype, hipStream_t stream);
+// bias + tanh-GELU forward / backward and bias-gradient column sums (bias_gelu.hip)
+constexpr int kBiasGeluMaxSlices = 2048;
+struct BiasGeluParams {
+    const void *x;       // fwd: (rows, cols) GEMM output;  bwd / column sum: the incoming gradient g
+    const void *bias;    // fwd: (cols) 16-bit or NULL
+    void *pre;           // fwd: optional (rows, cols) out = x + bias;  bwd: (rows, cols) in = saved pre-activation
+    void *y;             // fwd: gelu out;  bwd: dpre out (may alias x)
+    void *dbias;         // bwd: (cols) out, fp32 or 16-bit, may be NULL
+    float *ws;           // bwd: (slices, cols) fp32 partial sums (required when dbias != NULL)
+    int64_t rows;
+    int cols;
+    int dbias_f32;
+};
+hipError_t launch_bias_gelu_fwd(const BiasGeluParams &p, int dtype, hipStream_t stream);
+hipError_t launch_bias_gelu_bwd(const BiasGeluParams &p, int dtype, bool gelu, hipStream_t stream);
+int bias_gelu_bwd_slices(int64_t rows, int cols);
 hipError_t launch_flash_fwd(const FlashParams &p, int dtype, bool vec, hipStream_t stream);
 // LDS-DMA ring version; needs 16-byte friendly shapes (vec)
 hipError_t launch_flash_fwd_dma(const FlashParams &p, int dtype, hipStream_t stream);

@@ -396,13 +396,6 @@ __global__ __launch_bounds__(512) void sense_mix_dc_kernel(const MixBwdParams p)
         wait_vmcnt<0>();
     }
 
-    if (tid == 0) {
-        const unsigned prev = atomicAdd(&queues->done, 1u);
-        if (prev == gridDim.x - 1) {
-            for (int q = 0; q < 8; ++q) atomicExch(&queues->ticket[q], 0u);
-            atomicExch(&queues->done, 0u);
-        }
-    }
 }
 
 // =====================================================================================================================
@@ -797,24 +790,6 @@ __global__ __launch_bounds__(256) void sense_dk_kernel(const SenseGradParams p) 
 }
 
 // ---- launchers -------------------------------------------------------------------------------------------------
-constexpr int kBwdQueueRing = 64;
-__device__ MixQueues g_mix_bwd_queues[kBwdQueueRing];
-
-static MixQueues *next_bwd_queue_record() {
-    static std::atomic<unsigned> counter{0};
-    thread_local int cached_dev = -1;
-    thread_local MixQueues *base = nullptr;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    if (dev != cached_dev) {
-        void *ptr = nullptr;
-        if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_mix_bwd_queues)) != hipSuccess) return nullptr;
-        base = static_cast<MixQueues *>(ptr);
-        cached_dev = dev;
-    }
-    return base + (counter.fetch_add(1u, std::memory_order_relaxed) % kBwdQueueRing);
-}
-
 static int persistent_grid() {
     thread_local int cached_dev = -1, cus = 0;
     int dev = 0;
@@ -828,8 +803,8 @@ static int persistent_grid() {
 
 template <class ET, int KD>
 static hipError_t launch_dc_kd(MixBwdParams p, hipStream_t stream) {
-    p.queues = next_bwd_queue_record();
-    if (p.queues == nullptr) return hipErrorInvalidDevice;
+    const hipError_t armed = arm_mix_queues(p.queues, stream);   // sense_mix_dma.hip
+    if (armed != hipSuccess) return armed;
     const int njobs = p.b * p.n_chunks * p.n_ktiles;
     const int cus = persistent_grid();
     dim3 g(njobs < cus ? njobs : cus), t(512);

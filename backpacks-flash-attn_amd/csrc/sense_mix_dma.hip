@@ -23,8 +23,8 @@
 //     workgroups in order and round-robin: with one workgroup per CU and jobs of 4,3,2,1 units that gave rounds of
 //     4+3+2 = 9 units per CU against 7.5 ideal (dispatch_order probe); a static snake assignment lost
 //     to run-time variance (r01).  A group's tiles still prefer one XCD, i.e. one L2 holds its C tiles.
-//     Queue state: 64 bytes of device memory from a small ring owned by the library (self-resetting: the last
-//     workgroup to leave zeroes it), see launch_sense_mix_dma.
+//     Queue state: a 64-byte record of device memory, the caller's (`queue_ws`) or one of a small ring owned by the
+//     library, zeroed by a memset node in front of every launch, see arm_mix_queues.
 // Rows past the sequence are fetched from a clamped (valid) row: their probabilities are exactly 0 by the
 // causal mask and 0 * finite = 0.
 #include <atomic>
@@ -452,20 +452,15 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
         }
     }
 
-    // the last workgroup to run out of work re-arms the queues for the next launch
-    if (tid == 0) {
-        const unsigned prev = atomicAdd(&queues->done, 1u);
-        if (prev == gridDim.x - 1) {
-            for (int q = 0; q < 8; ++q) atomicExch(&queues->ticket[q], 0u);
-            atomicExch(&queues->done, 0u);
-        }
-    }
 }
 
-// Queue state for the persistent launch: a ring of 64-byte records in device memory owned by the library, one per
-// launch in flight (zero-initialised with the module; every launch leaves its record zeroed again).  Consecutive
-// launches take consecutive records, so two launches can only meet on one record if 64 of them are in flight
-// at once on different streams.
+// Queue state of a persistent launch: one 64-byte record of device memory, zeroed by a memset node enqueued right in
+// front of the kernel (stream-ordered, so it is captured into a HIP graph with the launch and a launch that died
+// cannot leave a stale record behind).  The record belongs to ONE launch until that launch has completed:
+//   * callers that capture graphs or run launches concurrently on several streams pass their own record
+//     (`queue_ws` of the C ABI; the Python binding always does -- a graph then owns the record it replays);
+//   * queue_ws == NULL takes the next record of a small ring owned by the library: enough for eager launches, which
+//     can only meet on one record if 64 of them are in flight at once.
 constexpr int kMixQueueRing = 64;
 __device__ MixQueues g_mix_queues[kMixQueueRing];
 
@@ -484,6 +479,13 @@ static MixQueues *next_queue_record() {
     return base + (counter.fetch_add(1u, std::memory_order_relaxed) % kMixQueueRing);
 }
 
+// shared with the dC launch (sense_mix_bwd.hip)
+hipError_t arm_mix_queues(MixQueues *&queues, hipStream_t stream) {
+    if (queues == nullptr) queues = next_queue_record();
+    if (queues == nullptr) return hipErrorInvalidDevice;
+    return hipMemsetAsync(queues, 0, sizeof(MixQueues), stream);
+}
+
 static int mix_persistent_grid() {
     thread_local int cached_dev = -1, cus = 0;
     int dev = 0;
@@ -497,8 +499,8 @@ static int mix_persistent_grid() {
 
 template <class ET, int KD>
 static hipError_t launch_kd(MixParams p, hipStream_t stream) {
-    p.queues = next_queue_record();
-    if (p.queues == nullptr) return hipErrorInvalidDevice;
+    const hipError_t armed = arm_mix_queues(p.queues, stream);
+    if (armed != hipSuccess) return armed;
     const int njobs = p.b * p.n_chunks * p.n_qtiles;
     const int cus = mix_persistent_grid();
     dim3 g(njobs < cus ? njobs : cus), t(512);   // 120 KB of LDS: one workgroup per CU

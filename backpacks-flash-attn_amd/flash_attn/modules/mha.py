@@ -3,6 +3,7 @@
 twins SelfAttention / CrossAttention (the reference's own non-fused path, any device), and MHA.
 ParallelMHA, rotary embeddings, dwconv and the Triton variants are out of scope."""
 import math
+from functools import partial
 
 import torch
 import torch.nn as nn
@@ -10,6 +11,7 @@ import torch.nn.functional as F
 
 from flash_attn.flash_attn_interface import (flash_attn_unpadded_kvpacked_func,
                                              flash_attn_unpadded_qkvpacked_func)
+from flash_attn.ops.fused_dense import FusedDense
 
 _NEG = -10000.0  # additive mask value of the eager path (reference mha.py:212,219)
 
@@ -163,15 +165,19 @@ class MHA(nn.Module):
         self.num_heads = num_heads
         assert embed_dim % num_heads == 0, 'embed_dim must be divisible by num_heads'
         self.head_dim = embed_dim // num_heads
-        # fused_bias_fc selected FusedDense upstream; its forward is F.linear (ops/fused_dense.py:52)
-        linear_cls = LinearResidual if return_residual else nn.Linear
-        self.Wqkv = linear_cls(embed_dim, 3 * embed_dim, bias=bias, **factory_kwargs)
+        # fused_bias_fc selects FusedDense, as upstream (mha.py:330-337): same parameters, bias gradient by bp_column_sum
+        linear_cls = FusedDense if fused_bias_fc else nn.Linear
+        if return_residual:
+            qkv_cls = partial(FusedDense, return_residual=True) if fused_bias_fc else LinearResidual
+        else:
+            qkv_cls = linear_cls
+        self.Wqkv = qkv_cls(embed_dim, 3 * embed_dim, bias=bias, **factory_kwargs)
         attn_cls = FlashSelfAttention if use_flash_attn else SelfAttention
         cross_cls = FlashCrossAttention if use_flash_attn else CrossAttention
         self.inner_attn = attn_cls(causal=causal, softmax_scale=softmax_scale, attention_dropout=dropout)
         self.inner_cross_attn = cross_cls(causal=causal, softmax_scale=softmax_scale,
                                           attention_dropout=dropout)
-        self.out_proj = nn.Linear(embed_dim, embed_dim, **factory_kwargs)
+        self.out_proj = linear_cls(embed_dim, embed_dim, **factory_kwargs)
 
     def forward(self, x, x_kv=None, key_padding_mask=None, cu_seqlens=None, max_seqlen=None,
                 inference_params=None, **kwargs):

@@ -28,6 +28,7 @@ import bp_hip
 from flash_attn.models.gpt import GPTModel, GPTPreTrainedModel, _activation, _init_weights, _pad_vocab
 from flash_attn.modules.block import Block
 from flash_attn.modules.mlp import FusedDenseGeluDense, Mlp
+from flash_attn.ops.fused_dense import FusedDense, fused_dense_func
 from flash_attn.ops.layer_norm import dropout_add_layer_norm
 from flash_attn.utils.pretrained import state_dict_from_pretrained
 from src.utils.generation import GenerationMixin
@@ -85,9 +86,8 @@ class ContextSelfAttn(nn.Module):
 
     def __init__(self, num_content_vectors, embed_dim, device=None, dtype=None, use_hip=False):
         super().__init__()
-        # the reference uses FusedDense here (:102); its forward is F.linear with the same
-        # parameter names (flash_attn/ops/fused_dense.py:110-129)
-        self.Wqkv = nn.Linear(embed_dim, 2 * embed_dim, device=device, dtype=dtype)
+        # FusedDense as in the reference (:102): nn.Linear's parameters, bias gradient by bp_column_sum in training
+        self.Wqkv = FusedDense(embed_dim, 2 * embed_dim, device=device, dtype=dtype)
         self.num_content_vectors = num_content_vectors
         self.softmax_scale = None
         self.use_hip = use_hip
@@ -106,7 +106,7 @@ class ContextSelfAttn(nn.Module):
             return self.Wqkv(encoded).reshape(b, s, 2, k, dk)
         w = F.pad(self.Wqkv.weight.view(2, k, dk, d), (0, 0, 0, pad)).view(2 * k * (dk + pad), d)
         bias = F.pad(self.Wqkv.bias.view(2, k, dk), (0, pad)).view(-1)
-        return F.linear(encoded, w, bias).view(b, s, 2, k, dk + pad)
+        return fused_dense_func(encoded, w, bias).view(b, s, 2, k, dk + pad)
 
     def scale(self):
         """softmax scale of the TRUE sense width d/k (reference :117), whatever `project` padded to."""

@@ -240,7 +240,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    # under torch.distributed.run (any world size, 1 included: the launch path is then the one the N-GPU runs take)
+    if world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ):
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=device)   # 'nccl' is RCCL on ROCm
 

@@ -7,10 +7,13 @@
  * and its Backpack-specific ops are eager ATen calls (training/src/models/backpack.py:107-122,313).
  * Every entry point below names the reference interface it replaces.  All of them
  *   - take raw DEVICE pointers, explicit sizes and int64 ELEMENT strides (no torch types),
- *   - allocate nothing and keep no caller-visible state (re-entrant; scratch is passed in by the caller).  The one
- *     piece of internal state: bp_sense_mix* / bp_sense_mix_dc launch persistent workgroups that pull jobs from
- *     ticket queues kept in a ring of 64-byte device records owned by the library (one record per launch in
- *     flight, consecutive launches take consecutive records, each launch leaves its record zeroed),
+ *   - allocate nothing and keep no caller-visible state (re-entrant; scratch is passed in by the caller).
+ *     bp_sense_mix* / bp_sense_mix_dc launch persistent workgroups that pull jobs from ticket queues in a 64-byte
+ *     record of device memory, `queue_ws` (BP_QUEUE_WS_BYTES, 16-byte aligned, contents undefined on entry: a
+ *     memset node in front of the kernel zeroes it on the stream; it must belong to this launch alone until the
+ *     launch has completed -- so a captured HIP graph owns the record it replays).  queue_ws == NULL takes the next
+ *     record of a 64-entry ring owned by the library: fine for eager launches, NOT for graph capture or for more
+ *     than 64 launches in flight,
  *   - enqueue on the given hipStream_t and return without synchronising,
  *   - return 0 on success or a negative BP_ERR_* (the Python layer raises RuntimeError, which
  *     is what TORCH_CHECK failures surface as in the reference: fmha_api.cpp:206-250).
@@ -24,7 +27,8 @@
 extern "C" {
 #endif
 
-#define BP_ABI_VERSION 2   /* 2: *_dropout entry points added (nothing removed or changed) */
+#define BP_ABI_VERSION 3   /* 2: *_dropout entry points added; 3: bias/GELU + column-sum entry points added, the
+                              persistent sense-mix launches take a caller-owned `queue_ws` */
 
 /* element type of q/k/v/out/content tensors */
 #define BP_DTYPE_F16 0
@@ -39,6 +43,8 @@ extern "C" {
 #define BP_ERR_LAUNCH -5      /* hipLaunchKernel failed (FMHA_CHECK_CUDA, src/fmha_utils.h:39)              */
 #define BP_ERR_DOUT -6        /* sense mix: d_out < 1                                                       */
 #define BP_ERR_DROPOUT -7     /* p_dropout outside [0,1), rng_state NULL with p > 0, or a shape the dropout path lacks */
+
+#define BP_QUEUE_WS_BYTES 64   /* `queue_ws` of the persistent sense-mix launches */
 
 typedef void *bp_stream_t; /* a hipStream_t */
 
@@ -168,6 +174,7 @@ int bp_sense_alpha(const void *qk, void *alpha, float *lse_ws, int lse_ready,
  *   out      (batch, seqlen, d_out) 16-bit, strides o_batch/o_row
  *   lse_ws   fp32 scratch, batch * nsenses * roundup(seqlen,16) elements
  *   lse_ready  as in bp_sense_alpha
+ *   queue_ws   BP_QUEUE_WS_BYTES of device memory for the persistent launch, or NULL (see the top of this file)
  */
 int bp_sense_mix(const void *qk, const void *content, void *out, float *lse_ws, int lse_ready,
                  int batch, int seqlen, int nsenses, int d_k, int d_out,
@@ -175,7 +182,7 @@ int bp_sense_mix(const void *qk, const void *content, void *out, float *lse_ws, 
                  int64_t qk_sense_stride,
                  int64_t c_batch_stride, int64_t c_row_stride, int64_t c_sense_stride,
                  int64_t o_batch_stride, int64_t o_row_stride,
-                 float softmax_scale, int dtype, bp_stream_t stream);
+                 float softmax_scale, int dtype, void *queue_ws, bp_stream_t stream);
 
 /*
  * bp_sense_mix_weighted -- bp_sense_mix with the intervention hook fused in:
@@ -199,7 +206,7 @@ int bp_sense_mix_weighted(const void *qk, const void *content, const float *key_
                           int64_t c_batch_stride, int64_t c_row_stride, int64_t c_sense_stride,
                           int64_t kw_batch_stride, int64_t kw_sense_stride,
                           int64_t o_batch_stride, int64_t o_row_stride,
-                          float softmax_scale, int dtype, bp_stream_t stream);
+                          float softmax_scale, int dtype, void *queue_ws, bp_stream_t stream);
 
 /*
  * bp_sense_mix_dc -- backward of bp_sense_mix with respect to the content:
@@ -217,7 +224,7 @@ int bp_sense_mix_dc(const void *qk, const void *dout, const float *lse, void *dc
                     int64_t qk_batch_stride, int64_t qk_row_stride, int64_t qk_two_stride, int64_t qk_sense_stride,
                     int64_t do_batch_stride, int64_t do_row_stride,
                     int64_t c_batch_stride, int64_t c_row_stride, int64_t c_sense_stride,
-                    float softmax_scale, int dtype, bp_stream_t stream);
+                    float softmax_scale, int dtype, void *queue_ws, bp_stream_t stream);
 
 /*
  * bp_sense_dq_dk -- backward of the sense weights with respect to qk, for ONE slab of 128 queries [t0, t0 + 128):
@@ -386,6 +393,30 @@ int bp_xentropy_fwd(const void *logits, const int64_t *labels, float *losses, fl
 int bp_xentropy_bwd(const float *grad_losses, const void *logits, const float *lse, const int64_t *labels,
                     void *grad_logits, int64_t rows, int cols, int64_t row_stride, int64_t grad_row_stride,
                     float smoothing, int total_classes, int dtype, bp_stream_t stream);
+
+/*
+ * bp_bias_gelu_fwd / bp_bias_gelu_bwd / bp_column_sum -- the elementwise halves of the reference's fused dense
+ * layers (flash_attn/ops/fused_dense.py:175-330 `FusedDenseGeluDenseFunc`, :27-108 `FusedDenseFunc`), i.e. what the
+ * cuBLASLt epilogues of csrc/fused_dense_lib do around the GEMMs (fused_dense.cpp:195-197: `linear_gelu_forward`,
+ * `bias_gelu_linear_dgrad_bgrad`, `linear_bias_wgrad`).  The GEMMs stay on the BLAS library.
+ *   forward   y = gelu_tanh(x + bias);  pre_out (optional) = x + bias rounded to 16 bit -- y is then the GELU of that
+ *             rounded value, so bp_bias_gelu_bwd differentiates exactly what the forward evaluated
+ *   backward  dpre = grad * gelu_tanh'(pre);   dbias[c] = sum_r dpre[r,c]   (one pass; deterministic two-stage sum)
+ *   column sum  dbias[c] = sum_r grad[r,c]     (bias gradient of a dense layer without activation)
+ * gelu_tanh(x) = 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))  (GPT-2 `gelu_new`, F.gelu(approximate='tanh')).
+ *   x, grad, pre, pre_out, y, dpre   (rows, cols) 16-bit contiguous, cols % 8 == 0, 16-byte aligned;
+ *                                    y may alias x, dpre may alias grad
+ *   bias    (cols) 16-bit or NULL (pre_out then must be NULL too: the pre-activation is x itself)
+ *   dbias   (cols) fp32 (dbias_is_f32) or 16-bit; NULL in bp_bias_gelu_bwd = no bias gradient wanted
+ *   ws      fp32 workspace of bp_bias_grad_ws_floats(rows, cols) elements (contents undefined on entry)
+ */
+int64_t bp_bias_grad_ws_floats(int64_t rows, int cols);
+int bp_bias_gelu_fwd(const void *x, const void *bias, void *pre_out, void *y, int64_t rows, int cols, int dtype,
+                     bp_stream_t stream);
+int bp_bias_gelu_bwd(const void *grad, const void *pre, void *dpre, void *dbias, float *ws, int64_t rows, int cols,
+                     int dtype, int dbias_is_f32, bp_stream_t stream);
+int bp_column_sum(const void *grad, void *dbias, float *ws, int64_t rows, int cols, int dtype, int dbias_is_f32,
+                  bp_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -35,7 +35,8 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    ddp = world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ)   # under torch.distributed.run
+    if ddp:
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=dev)
     from bench import MODELS
@@ -48,7 +49,7 @@ def main():
     torch.manual_seed(0)
     model = BackpackLMHeadModel(cfg, device=dev, dtype=torch.bfloat16 if a.pure_bf16 else torch.float32).train()
     net = model
-    if world > 1:
+    if ddp:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True,
                                                         find_unused_parameters=False)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True)
@@ -68,15 +69,19 @@ def main():
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if ddp:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if ddp:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if ddp:   # the slowest rank's clock, as bench.py reports
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
     if rank == 0:
         print(json.dumps({'metric': f'tokens/sec train step (fwd+loss+bwd+AdamW), Backpack-{a.model} seq={a.seq}',
                           'value': round(world * a.batch * a.seq * a.steps / dt, 1), 'unit': 'tokens/s',
@@ -84,7 +89,11 @@ def main():
                           'dtype': 'bf16' if a.pure_bf16 else 'bf16 autocast over fp32 parameters', 'dropout': a.dropout,
                           'grad_allreduce_bytes': sum(p.numel() * p.element_size() for p in model.parameters()),
                           'loss': round(float(loss.detach()), 4),
-                          'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}))
+                          'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                          'launch': 'torch.distributed.run, DDP over nccl (RCCL)' if ddp else 'single process'}))
+    if ddp:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

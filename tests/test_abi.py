@@ -68,8 +68,11 @@ def test_argument_validation_returns_before_any_launch():
     assert h.bp_flash_fwd_dropout(p, p, p, p, p, null, null, *tail, 0.1, null, null) == -7
     assert h.bp_flash_fwd_dropout(p, p, null, null, p, null, null, *tail, 0.1, p, null) == -7
     # sense mix: d_out < 1, d_k out of range
-    assert h.bp_sense_mix(p, p, p, p, 0, 1, 16, 4, 16, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0.25, 1, null) == -6
-    assert h.bp_sense_mix(p, p, p, p, 0, 1, 16, 4, 200, 64, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0.25, 1, null) == -2
+    assert h.bp_sense_mix(p, p, p, p, 0, 1, 16, 4, 16, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0.25, 1, null, null) == -6
+    assert h.bp_sense_mix(p, p, p, p, 0, 1, 16, 4, 200, 64, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0.25, 1, null, null) == -2
+    # a misaligned queue_ws
+    assert h.bp_sense_mix(p, p, p, p, 0, 1, 16, 4, 16, 64, 8, 8, 8, 8, 8, 8, 8, 8, 8, 0.25, 1, ctypes.c_void_p(0x1004),
+                          null) == -3
     assert h.bp_sense_alpha(p, null, p, 0, 1, 16, 4, 16, 1, 1, 1, 1, 0.25, 1, null) == -3
     assert h.bp_sense_lse(p, p, 1, 0, 4, 16, 1, 1, 1, 1, 0.25, 1, null) == -3
     assert h.bp_attn_probs(p, p, p, p, 1, 1, 64, 16, 0, 1, 1, 1, 1, 1, 1, 16, 1, 1, 1, 0.125, 1, 1,
@@ -93,12 +96,12 @@ def test_argument_validation_returns_before_any_launch():
 
     # fused sense-mix backward: d_k not a multiple of 8, d_out not a multiple of 8, null dcontent, odd stride, bad scale
     mix_st = (64,) * 9
-    assert h.bp_sense_mix_dc(p, p, p, p, 1, 16, 4, 10, 64, *mix_st, 0.25, 1, null) == -2
-    assert h.bp_sense_mix_dc(p, p, p, p, 1, 16, 4, 16, 20, *mix_st, 0.25, 1, null) == -6
-    assert h.bp_sense_mix_dc(p, p, p, null, 1, 16, 4, 16, 64, *mix_st, 0.25, 1, null) == -3
-    assert h.bp_sense_mix_dc(p, p, p, p, 1, 16, 4, 16, 64, 64, 63, 64, 64, 64, 64, 64, 64, 64, 0.25, 1, null) == -3
-    assert h.bp_sense_mix_dc(p, p, p, p, 1, 16, 4, 16, 64, *mix_st, 0.0, 1, null) == -4
-    assert h.bp_sense_mix_dc(p, p, p, p, 1, 16, 4, 16, 64, *mix_st, 0.25, 9, null) == -1
+    assert h.bp_sense_mix_dc(p, p, p, p, 1, 16, 4, 10, 64, *mix_st, 0.25, 1, null, null) == -2
+    assert h.bp_sense_mix_dc(p, p, p, p, 1, 16, 4, 16, 20, *mix_st, 0.25, 1, null, null) == -6
+    assert h.bp_sense_mix_dc(p, p, p, null, 1, 16, 4, 16, 64, *mix_st, 0.25, 1, null, null) == -3
+    assert h.bp_sense_mix_dc(p, p, p, p, 1, 16, 4, 16, 64, 64, 63, 64, 64, 64, 64, 64, 64, 64, 0.25, 1, null, null) == -3
+    assert h.bp_sense_mix_dc(p, p, p, p, 1, 16, 4, 16, 64, *mix_st, 0.0, 1, null, null) == -4
+    assert h.bp_sense_mix_dc(p, p, p, p, 1, 16, 4, 16, 64, *mix_st, 0.25, 9, null, null) == -1
     # dq/dk slab kernel: slab start not a multiple of 128 / past the end, null workspace, fp32 stride not 16-byte
     dq_st = (64,) * 11
     assert h.bp_sense_dq_dk(p, p, p, p, p, p, 1, 256, 4, 16, 64, *dq_st, 0.25, 1, null) == -3
@@ -116,6 +119,17 @@ def test_argument_validation_returns_before_any_launch():
     assert h.bp_dropout_add_layer_norm_bwd(p, p, p, p, p, p, p, p, p, 8, 64, 1e-5, 1, 0, 1, 1, 1.5, p, null) == -7
     assert h.bp_dropout_add_layer_norm_bwd(p, p, p, p, p, p, p, p, p, 8, 64, 1e-5, 1, 1, 0, 1, 0.0, null, null) == -1
     assert h.bp_dropout_add_layer_norm_bwd(p, p, p, p, p, p, p, p, null, 8, 64, 1e-5, 1, 0, 1, 1, 0.0, null, null) == -3
+    # bias + GELU / column sums: columns not a multiple of 8, pre_out without a bias, a bias gradient without workspace,
+    # fp32 "16-bit" dtype; the workspace size is a pure function of the shape
+    assert h.bp_bias_gelu_fwd(p, p, null, p, 8, 60, 1, null) == -3
+    assert h.bp_bias_gelu_fwd(p, null, p, p, 8, 64, 1, null) == -3
+    assert h.bp_bias_gelu_fwd(p, p, null, p, 8, 64, 2, null) == -1
+    assert h.bp_bias_gelu_bwd(p, p, p, p, null, 8, 64, 1, 1, null) == -3
+    assert h.bp_bias_gelu_bwd(p, null, p, null, null, 8, 64, 1, 1, null) == -3
+    assert h.bp_column_sum(p, null, p, 8, 64, 1, 1, null) == -3
+    assert h.bp_column_sum(p, p, p, 0, 64, 1, 1, null) == -3
+    assert h.bp_bias_grad_ws_floats(32768, 3072) == 3072 * 1366 and h.bp_bias_grad_ws_floats(3, 768) == 768 * 2
+    assert h.bp_bias_grad_ws_floats(0, 768) == 0
 
 
 def test_philox_restatement_known_answers():

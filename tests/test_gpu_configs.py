@@ -210,3 +210,99 @@ def test_flash_varlen_sweep(seqlen, d, causal, dtype):
     assert gerr <= 4 * gbase + 1e-4, ('dqkv', gerr, gbase)
     # padded rows: zero output, zero gradient (bit-exact)
     assert torch.count_nonzero(out[~mask.to(DEV)]) == 0 and torch.count_nonzero(dqkv[~mask.to(DEV)]) == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE config 3 readiness on ONE GPU: the per-GPU training workload at its real dimensions, and the launch path
+# ---------------------------------------------------------------------------------------------------------------
+def test_small_config3_training_step_seq1024():
+    """Config 3's per-GPU workload: Backpack-Small, S = 1024, the reference's recipe (fp32 parameters under bf16
+    autocast, training/configs/trainer/default.yaml precision 16), dropout 0, ONE forward + fused cross-entropy +
+    backward through all 12 layers of flash-bwd / LayerNorm-bwd / fused dense / sense-mix-bwd.  Loss and the gradients
+    of ten named parameters against fp32 autograd of the eager twin (use_flash_attn and every fused flag off, fp32, no
+    autocast); criterion of the reference's gradient tests (tests/test_flash_attn.py:435-437): error <= 4 x the
+    error of the eager twin under the same bf16 autocast."""
+    from flash_attn.losses.cross_entropy import CrossEntropyLoss
+    from src.models.backpack import BackpackConfig, BackpackLMHeadModel
+    kw = dict(n_embd=768, n_head=12, n_layer=12, num_content_vectors=16, vocab_size=50257, n_positions=1024,
+              scale_attn_by_inverse_layer_idx=True, resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0,
+              pad_vocab_size_multiple=8)
+    torch.manual_seed(21)
+    eager = BackpackLMHeadModel(BackpackConfig(use_flash_attn=False, **kw), device=DEV).train()
+    with torch.no_grad():   # default init gives near-uniform attention; sharpen so the softmax backward matters
+        eager.transformer.contextualization_attn.Wqkv.weight.mul_(8.0)
+        for layer in eager.transformer.gpt2_model.layers:
+            layer.mixer.Wqkv.weight.mul_(6.0)
+    hip = BackpackLMHeadModel(BackpackConfig(use_flash_attn=True, fused_dropout_add_ln=True, fused_bias_fc=True,
+                                             fused_dense_gelu_dense=True, **kw), device=DEV).train()
+    hip.load_state_dict(eager.state_dict())
+    ids = torch.randint(0, 50257, (1, 1024), device=DEV, generator=torch.Generator(device=DEV).manual_seed(0))
+    labels = torch.roll(ids, -1, 1).reshape(-1)
+    names = ['transformer.gpt2_model.layers.0.mixer.Wqkv.weight', 'transformer.gpt2_model.layers.11.mixer.Wqkv.weight',
+             'transformer.gpt2_model.layers.5.mixer.out_proj.bias', 'transformer.gpt2_model.layers.3.mlp.fc1.bias',
+             'transformer.gpt2_model.layers.7.mlp.fc2.weight', 'transformer.contextualization_attn.Wqkv.weight',
+             'transformer.contextualization_attn.Wqkv.bias', 'transformer.content_model.final_mlp.fc2.weight',
+             'transformer.content_model.final_mlp.fc1.bias', 'transformer.gpt2_model.embeddings.word_embeddings.weight',
+             'transformer.gpt2_model.layers.6.norm1.weight', 'transformer.gpt2_model.embeddings.position_embeddings.weight']
+
+    def run(model, autocast, fused_loss):
+        model.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
+            logits = model(ids).logits
+        flat = logits.reshape(-1, logits.shape[-1])
+        loss = CrossEntropyLoss()(flat, labels) if fused_loss else torch.nn.functional.cross_entropy(flat.float(), labels)
+        loss.backward()
+        params = dict(model.named_parameters())
+        return loss.item(), {n: params[n].grad.detach().float().cpu() for n in names}
+
+    l_ref, g_ref = run(eager, False, False)
+    l_low, g_low = run(eager, True, False)
+    eager.zero_grad(set_to_none=True)
+    l_hip, g_hip = run(hip, True, True)
+    print(f'config-3 step: loss fp32 {l_ref:.5f} eager-amp {l_low:.5f} hip-amp {l_hip:.5f}')
+    assert abs(l_hip - l_ref) <= 4 * abs(l_low - l_ref) + 5e-3
+    for n in names:
+        r = g_ref[n]
+        err, base = (g_hip[n] - r).abs().max().item(), (g_low[n] - r).abs().max().item()
+        scale = r.abs().max().item()
+        print(f'  {n}: hip {err:.3e} eager-amp {base:.3e} |ref| {scale:.3e}')
+        assert torch.isfinite(g_hip[n]).all() and scale > 0, n
+        assert err <= 4 * base + 1e-3 * scale, (n, err, base, scale)
+    for p in hip.parameters():
+        assert p.grad is not None and p.grad.dtype == torch.float32
+
+
+def _torchrun(script_args, timeout=900):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
+           '127.0.0.1', '--master-port', '29533'] + script_args
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    import json
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_launch_path_under_torchrun():
+    """The driver's N-GPU launch line with N = 1: `python -m torch.distributed.run ... bench.py --gpus 1` goes through
+    init_process_group('nccl'), the batch broadcast, the barriers and the MAX all-reduce of the elapsed time -- the code
+    the 8-GPU run depends on -- and prints ONE JSON line with the contract's fields."""
+    line = _torchrun(['bench.py', '--gpus', '1', '--steps', '2', '--warmup', '1', '--batch', '8', '--no-cpu-baseline'])
+    assert line['n_gpus'] == 1 and line['steps'] == 2 and line['unit'] == 'tokens/s' and line['value'] > 0
+    assert line['config']['batch_per_gpu'] == 8 and line['scaling'] == 'weak' and 'roofline' in line
+    line = _torchrun(['bench.py', '--gpus', '1', '--steps', '1', '--warmup', '1', '--batch', 'auto', '--batch-candidates',
+                      '4,8', '--no-cpu-baseline'])
+    assert line['config']['batch_per_gpu'] in (4, 8) and len(line['batch_sweep']) == 2
+
+
+def test_train_step_launch_path_under_torchrun():
+    """scripts/bench_train_step.py the same way: DDP over nccl (RCCL) with the reference's flags, one rank."""
+    line = _torchrun(['scripts/bench_train_step.py', '--batch', '2', '--steps', '1', '--warmup', '1'])
+    assert line['n_gpus'] == 1 and line['value'] > 0 and line['launch'].startswith('torch.distributed.run')
+    assert line['grad_allreduce_bytes'] > 680e6 and line['loss'] > 0

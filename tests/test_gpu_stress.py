@@ -92,3 +92,73 @@ def test_persistent_mix_launches_on_several_streams():
         torch.cuda.synchronize()
         for out, (_, _, _, want) in zip(outs, data):
             assert torch.equal(out, want), f'round {rnd}: a concurrent launch produced a different result'
+
+
+def test_persistent_mix_graphs_and_eager_launches_interleaved():
+    """Two captured HIP graphs and eager launches on three streams, 200 interleaved replays: every launch owns its
+    64-byte ticket record (`queue_ws`: the binding allocates one per call, so a graph replays its own), a memset node
+    re-arms it in front of the kernel, and no two launches can ever share tickets -- all results bit-identical."""
+    bp = _bp()
+    torch.manual_seed(8)
+    shapes = [(3, 512, 16, 48, 768), (2, 1024, 16, 48, 256), (4, 300, 4, 24, 104)]
+    data = []
+    for b, s, k, dk, d in shapes:
+        qk = (torch.randn(b, s, 2, k, dk, device=DEV) * 0.9).bfloat16()
+        c = torch.randn(b, s, k, d, device=DEV).bfloat16()
+        dout = torch.randn(b, s, d, device=DEV).bfloat16()
+        lse = bp.sense_lse(qk)
+        data.append((qk, c, dout, lse, bp.sense_mix(qk, c, lse=lse).clone(),
+                     bp.sense_mix_dc(qk, dout, lse, dk ** -0.5, c).clone(), dk))
+    torch.cuda.synchronize()
+    graphs = []
+    for qk, c, dout, lse, _, _, dk in data[:2]:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            bp.sense_mix(qk, c, lse=lse)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = bp.sense_mix(qk, c, lse=lse)
+            dc = bp.sense_mix_dc(qk, dout, lse, dk ** -0.5, c)
+        graphs.append((g, out, dc))
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    for rnd in range(200):
+        outs = []
+        for i, st in enumerate(streams):
+            qk, c, dout, lse, _, _, dk = data[(i + rnd) % 3]
+            with torch.cuda.stream(st):
+                outs.append(((i + rnd) % 3, bp.sense_mix(qk, c, lse=lse), bp.sense_mix_dc(qk, dout, lse, dk ** -0.5, c)))
+        for g, _, _ in graphs:
+            g.replay()                       # on the current stream, concurrent with the three side streams
+        if rnd % 20 == 19:
+            torch.cuda.synchronize()
+            for j, out, dc in outs:
+                assert torch.equal(out, data[j][4]) and torch.equal(dc, data[j][5]), f'eager launch, round {rnd}'
+            for (g, out, dc), d in zip(graphs, data):
+                assert torch.equal(out, d[4]) and torch.equal(dc, d[5]), f'graph replay, round {rnd}'
+    torch.cuda.synchronize()
+
+
+def test_raw_abi_mix_with_and_without_queue_ws():
+    """C ABI directly: queue_ws = NULL (the library's ring) and a caller-owned, deliberately dirty record give the
+    same bits."""
+    import ctypes
+    bp = _bp()
+    torch.manual_seed(9)
+    b, s, k, dk, d = 2, 512, 16, 48, 768
+    qk = torch.randn(b, s, 2, k, dk, device=DEV).bfloat16()
+    c = torch.randn(b, s, k, d, device=DEV).bfloat16()
+    want = bp.sense_mix(qk, c)
+    ws = torch.empty(b, k, s, dtype=torch.float32, device=DEV)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for queue in (None, torch.full((16,), 0x7fffffff, dtype=torch.int32, device=DEV)):
+        out = torch.zeros(b, s, d, device=DEV, dtype=torch.bfloat16)
+        for _ in range(3):       # the dirty record is re-armed by every launch
+            rc = bp.lib().bp_sense_mix(qk.data_ptr(), c.data_ptr(), out.data_ptr(), ws.data_ptr(), 0, b, s, k, dk, d,
+                                       qk.stride(0), qk.stride(1), qk.stride(2), qk.stride(3), c.stride(0), c.stride(1),
+                                       c.stride(2), out.stride(0), out.stride(1), dk ** -0.5, 1,
+                                       queue.data_ptr() if queue is not None else None, stream)
+            assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)
