@@ -234,8 +234,9 @@ def flash_bwd(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seql
     lse_len = softmax_lse.shape[-1]
     if out.stride(-1) != 1:
         out = out.contiguous()
-    # workspace for D_i = sum_d dO_i[d] * O_i[d] (filled by the dQ kernel, read by the dK/dV kernel)
-    dsum = torch.empty((batch, nheads, lse_len), dtype=torch.float32, device=q.device)
+    # workspace for the row statistics -D_i = -sum_d dO_i[d] * O_i[d] and -L_i / scale (filled by the dQ kernel, read
+    # by the dK/dV kernel)
+    dsum = torch.empty((batch, nheads, 2, lse_len), dtype=torch.float32, device=q.device)
     with torch.cuda.device(q.device):
         code = lib().bp_flash_bwd_dropout(
             dout.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),

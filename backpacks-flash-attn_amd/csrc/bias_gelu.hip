@@ -12,9 +12,9 @@
 // epilogue and `F.gelu(approximate='tanh')` use.  tanh(u) = 1 - 2 / (1 + e^(2u)) through v_exp_f32 / v_rcp_f32.
 //
 // Layout: rows x cols 16-bit, unit column stride, cols % 8 == 0; a thread owns 8 consecutive columns (one 16-byte
-// access per row), a 128-thread workgroup 1024 columns.  The column sums are deterministic, two stages, no atomics:
-// workgroup (chunk, slice) walks rows slice, slice + n_slices, ... with its 8 sums in registers and writes one partial
-// row; the second kernel adds the partial rows in a fixed order.  Bytes per element: forward 2 read + 2 (or 4)
+// access per row).  The column sums are deterministic, two stages, no atomics: workgroup (chunk of 512 columns, slice)
+// walks its rows with the 8 sums per lane in registers and writes one partial row; the second kernel adds the partial
+// rows in a fixed order.  Bytes per element: forward 2 read + 2 (or 4)
 // written, backward 4 read + 2 written, column sum 2 read.
 #include "bp_common.h"
 #include "bp_kernels.h"
@@ -88,11 +88,16 @@ __global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(const BiasGeluParams
 }
 
 // ---- backward / column sums --------------------------------------------------------------------------------------
-// grid (column chunks of 1024, slices); GELU = false: plain column sums of g (no pre, no dpre)
-template <class ET, bool GELU>
-__global__ __launch_bounds__(128) void bias_gelu_bwd_kernel(const BiasGeluParams p) {
-    const int col = (blockIdx.x * 128 + threadIdx.x) * 8;
-    if (col >= p.cols) return;
+// grid (column chunks of 512, slices), 4 waves: every wave owns the SAME 512 columns (a lane: 8 consecutive ones) and
+// every fourth row of the slice's rows, U rows per trip so that enough loads are in flight to cover the HBM latency
+// (U x 1 KB per wave; two rows per trip reached 1.4 TB/s, r03_b); the four waves' sums meet in LDS in a fixed order.
+// GELU = false: plain column sums of g (no pre, no dpre).
+template <class ET, bool GELU, int U>
+__global__ __launch_bounds__(256) void bias_gelu_bwd_kernel(const BiasGeluParams p) {
+    __shared__ float red[3][64][9];   // waves 1..3 -> wave 0 (pitch 9: conflict-free column access)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = (blockIdx.x * 64 + lane) * 8;
+    const bool active = col < p.cols;
     const int64_t cpr = p.cols / 8;
     const u32x4 *g = static_cast<const u32x4 *>(p.x) + col / 8;
     const u32x4 *pre = static_cast<const u32x4 *>(p.pre) + col / 8;
@@ -100,69 +105,89 @@ __global__ __launch_bounds__(128) void bias_gelu_bwd_kernel(const BiasGeluParams
     float sum[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) sum[j] = 0.f;
-    const int nsl = gridDim.y;
-    int64_t r = blockIdx.y;
-    // two rows per trip: both loads are in flight before the first exp
-    for (; r + nsl < p.rows; r += 2 * nsl) {
-        const u32x4 g0 = g[r * cpr], g1 = g[(r + nsl) * cpr];
-        float a[8], b[8];
-        unpack8<ET>(g0, a);
-        unpack8<ET>(g1, b);
-        if (GELU) {
-            const u32x4 x0 = pre[r * cpr], x1 = pre[(r + nsl) * cpr];
-            float xa[8], xb[8];
-            unpack8<ET>(x0, xa);
-            unpack8<ET>(x1, xb);
+    const int64_t step = (int64_t)gridDim.y * 4;
+    if (active) {
+        int64_t r = (int64_t)blockIdx.y * 4 + wave;
+        for (; r + (U - 1) * step < p.rows; r += U * step) {
+            u32x4 gw[U], xw[GELU ? U : 1];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { a[j] *= gelu_grad(xa[j]); b[j] *= gelu_grad(xb[j]); }
-            const u32x4 w0 = pack8<ET>(a), w1 = pack8<ET>(b);
-            dpre[r * cpr] = w0;
-            dpre[(r + nsl) * cpr] = w1;
-            unpack8<ET>(w0, a);   // dbias sums the rounded values the weight-gradient GEMM will see
-            unpack8<ET>(w1, b);
+            for (int u = 0; u < U; ++u) {
+                gw[u] = g[(r + u * step) * cpr];
+                if (GELU) xw[u] = pre[(r + u * step) * cpr];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float a[8];
+                unpack8<ET>(gw[u], a);
+                if (GELU) {
+                    float xa[8];
+                    unpack8<ET>(xw[u], xa);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a[j] *= gelu_grad(xa[j]);
+                    const u32x4 w = pack8<ET>(a);
+                    dpre[(r + u * step) * cpr] = w;
+                    unpack8<ET>(w, a);   // dbias sums the rounded values the weight-gradient GEMM will see
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sum[j] += a[j];
+            }
         }
+        for (; r < p.rows; r += step) {
+            float a[8];
+            unpack8<ET>(g[r * cpr], a);
+            if (GELU) {
+                float xa[8];
+                unpack8<ET>(pre[r * cpr], xa);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sum[j] += a[j] + b[j];
-    }
-    if (r < p.rows) {
-        float a[8];
-        unpack8<ET>(g[r * cpr], a);
-        if (GELU) {
-            float xa[8];
-            unpack8<ET>(pre[r * cpr], xa);
+                for (int j = 0; j < 8; ++j) a[j] *= gelu_grad(xa[j]);
+                const u32x4 w = pack8<ET>(a);
+                dpre[r * cpr] = w;
+                unpack8<ET>(w, a);
+            }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] *= gelu_grad(xa[j]);
-            const u32x4 w0 = pack8<ET>(a);
-            dpre[r * cpr] = w0;
-            unpack8<ET>(w0, a);
+            for (int j = 0; j < 8; ++j) sum[j] += a[j];
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sum[j] += a[j];
     }
-    if (p.ws != nullptr) {
+    if (p.ws == nullptr) return;
+    if (wave > 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[wave - 1][lane][j] = sum[j];
+    }
+    __syncthreads();
+    if (wave == 0 && active) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum[j] += red[w][lane][j];
         float *out = p.ws + (int64_t)blockIdx.y * p.cols + col;
         *reinterpret_cast<f32x4 *>(out) = f32x4{sum[0], sum[1], sum[2], sum[3]};
         *reinterpret_cast<f32x4 *>(out + 4) = f32x4{sum[4], sum[5], sum[6], sum[7]};
     }
 }
 
-// second stage: dbias[c] = sum over the partial rows, fixed order; one thread per column, 4 independent chains
+// second stage: dbias[c] = sum over the partial rows, fixed order.  A workgroup owns 64 columns: thread = (column quad,
+// one of 16 row groups), 16-byte loads, the 16 groups meet in LDS.
 template <class ET>
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const BiasGeluParams p, int nsl) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= p.cols) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int i = 0;
-    for (; i + 3 < nsl; i += 4) {
-        s0 += p.ws[(int64_t)i * p.cols + c];
-        s1 += p.ws[(int64_t)(i + 1) * p.cols + c];
-        s2 += p.ws[(int64_t)(i + 2) * p.cols + c];
-        s3 += p.ws[(int64_t)(i + 3) * p.cols + c];
+    __shared__ float red[16][16][5];
+    const int cq = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cq * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (c < p.cols)
+        for (int i = grp; i < nsl; i += 16) acc += *reinterpret_cast<const f32x4 *>(p.ws + (int64_t)i * p.cols + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[grp][cq][j] = acc[j];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int col = blockIdx.x * 64 + threadIdx.x;
+        if (col < p.cols) {
+            float s = 0.f;
+#pragma unroll
+            for (int gi = 0; gi < 16; ++gi) s += red[gi][threadIdx.x >> 2][threadIdx.x & 3];
+            if (p.dbias_f32) static_cast<float *>(p.dbias)[col] = s;
+            else static_cast<uint16_t *>(p.dbias)[col] = Elem<ET>::from_float(s);
+        }
     }
-    for (; i < nsl; ++i) s0 += p.ws[(int64_t)i * p.cols + c];
-    const float s = (s0 + s1) + (s2 + s3);
-    if (p.dbias_f32) static_cast<float *>(p.dbias)[c] = s;
-    else static_cast<uint16_t *>(p.dbias)[c] = Elem<ET>::from_float(s);
 }
 
 template <class ET>
@@ -182,23 +207,23 @@ hipError_t launch_bias_gelu_fwd(const BiasGeluParams &p, int dtype, hipStream_t 
 }
 
 int bias_gelu_bwd_slices(int64_t rows, int cols) {
-    const int chunks = (cols + 1023) / 1024;
-    int64_t nsl = (4096 + chunks - 1) / chunks;   // ~4096 workgroups of 2 waves: 32 waves per CU
+    const int chunks = (cols + 511) / 512;
+    int64_t nsl = (1024 + chunks - 1) / chunks;   // ~1024 workgroups of 4 waves: 16 waves per CU, 4-8 rows in flight each
     if (nsl > kBiasGeluMaxSlices) nsl = kBiasGeluMaxSlices;
-    if (nsl > (rows + 1) / 2) nsl = (rows + 1) / 2;   // at least two rows per slice where there are that many
+    if (nsl > (rows + 3) / 4) nsl = (rows + 3) / 4;   // a row per wave at least, where there are that many
     return (int)(nsl < 1 ? 1 : nsl);
 }
 
 template <class ET>
 static hipError_t bwd_et(const BiasGeluParams &p, bool gelu, hipStream_t stream) {
-    const int chunks = (p.cols + 1023) / 1024;
+    const int chunks = (p.cols + 511) / 512;
     const int nsl = bias_gelu_bwd_slices(p.rows, p.cols);
-    dim3 g(chunks, nsl), t(128);
-    if (gelu) hipLaunchKernelGGL((bias_gelu_bwd_kernel<ET, true>), g, t, 0, stream, p);
-    else hipLaunchKernelGGL((bias_gelu_bwd_kernel<ET, false>), g, t, 0, stream, p);
+    dim3 g(chunks, nsl), t(256);
+    if (gelu) hipLaunchKernelGGL((bias_gelu_bwd_kernel<ET, true, 4>), g, t, 0, stream, p);
+    else hipLaunchKernelGGL((bias_gelu_bwd_kernel<ET, false, 8>), g, t, 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || p.dbias == nullptr) return e;
-    hipLaunchKernelGGL((colsum_finish_kernel<ET>), dim3((p.cols + 255) / 256), dim3(256), 0, stream, p, nsl);
+    hipLaunchKernelGGL((colsum_finish_kernel<ET>), dim3((p.cols + 63) / 64), dim3(256), 0, stream, p, nsl);
     return hipGetLastError();
 }
 

@@ -186,7 +186,7 @@ struct LnBwdParams {
 };
 hipError_t launch_add_layer_norm_bwd(const LnBwdParams &p, int dtype, hipStream_t stream);
 // bias + tanh-GELU forward / backward and bias-gradient column sums (bias_gelu.hip)
-constexpr int kBiasGeluMaxSlices = 2048;
+constexpr int kBiasGeluMaxSlices = 1024;
 struct BiasGeluParams {
     const void *x;       // fwd: (rows, cols) GEMM output;  bwd / column sum: the incoming gradient g
     const void *bias;    // fwd: (cols) 16-bit or NULL

@@ -10,20 +10,33 @@
 //     dQ_i  = scale * sum_j dS_ij k_j               dK_j = scale * sum_i dS_ij q_i
 // With attention dropout (training; reference fmha_dgrad_kernel_1xN_loop.h:405-711 regenerates its Philox mask the
 // same way): Z_ij = keep_ij / (1 - p) from bp_philox.h, the forward's mask bit for bit, and
-//     dV_j = sum_i Z_ij P_ij dO_i                   dP_ij = Z_ij (dO_i . v_j)        (D_i already carries Z through O)
+//     dV_j = sum_i Z_ij P_ij dO_i                   dS_ij = P_ij (Z_ij dP_ij - D_i)   (D_i already carries Z through O)
 //
 // Two kernels, both deterministic (no atomics -- the reference's sequence-parallel variant adds dQ
 // with atomics and is only allclose-reproducible, tests/test_flash_attn.py:768-772):
-//   * dkdv: a wave owns 32 KEYS; K and V live in registers as MFMA B operands; it sweeps the query
-//     tiles that can see those keys.  S = Q K^T and dP = dO V^T come out with lane = key and the
-//     queries along the registers, which is exactly the B-operand layout of the two products that
-//     contract over queries (dV^T = dO^T P, dK^T = Q^T dS); their A operands are transposing LDS reads.
-//   * dq (runs FIRST): a wave owns 32 QUERIES (Q, dO, L, D in registers); it sweeps key tiles as the forward
-//     does: S^T = K Q^T, dP^T = V dO^T, dS^T feeds dQ^T = K^T dS^T.  Its prologue forms D for its rows from
-//     the dO and O fragments it holds anyway and publishes it for the dkdv kernel (which follows on the same
-//     stream), so no separate reduction pass over dO and O is needed.
-// A tile that is read both row-wise (ds_read_b128) and transposed (ds_read_b64_tr_b16) is kept as two
-// LDS images, each with the swizzle its read pattern needs; tiles arrive by the LDS-DMA ring (bp_dma.h).
+//   * dq (runs FIRST): a wave owns 32 QUERIES (Q, dO in registers); it sweeps key tiles as the forward does:
+//     S^T = K Q^T, dP^T = V dO^T, dS^T feeds dQ^T = K^T dS^T.  Its prologue forms D for its rows from the dO and O
+//     fragments it holds anyway and publishes -D and -L / scale for the dkdv kernel (same stream).
+//   * dkdv: a wave owns 32 KEYS; K and V live in registers as MFMA B operands; it sweeps the query tiles that can
+//     see those keys.  S = Q K^T and dP = dO V^T come out with lane = key and the queries along the registers,
+//     which is exactly the B-operand layout of the two products that contract over queries (dV^T = dO^T P,
+//     dK^T = Q^T dS); their A operands are transposing LDS reads.
+// What the round-2 version of this file spent its time on (r03_a PMC: 15-16 VALU + 6 SALU per MFMA, three times
+// the tile body's floor) and what replaced it:
+//   * ONE LDS image per streamed tile serves both read patterns -- row-wise ds_read_b128 (A operand of the
+//     products that contract over the head dimension) and ds_read_b64_tr_b16 (A operand of the products that
+//     contract over the tile's rows): 16-byte slot s of row r lives at slot s ^ swz(r), with swz chosen so that
+//     the 16 rows of a b128 pass hit 16 different 4-bank groups AND the 4 rows of a transposing pass lie in the
+//     4 different bank quarters (bwd_swz below).  Half the DMA instructions, half the LDS of the two-image form.
+//   * DMA in the "saddr" form: scalar tile pointer advanced on the scalar unit, per-lane byte offsets fixed at
+//     kernel start (a second, clamped set for the one partial tile a sweep can meet) -- zero VALU per tile.
+//   * -L / scale and -D are not subtracted per element: they are the INITIAL VALUE of the S and dP MFMA
+//     accumulators (dq: two constant register vectors as the C operand of the first MFMA; dkdv: the per-query
+//     values are read from the tile's statistics straight into the accumulator registers).  A score element then
+//     costs  mul, exp, mul  and the packs.
+//   * two tile bodies per kernel, in sequential loops with one body each: the clean body (every (query, key) pair
+//     of the wave's sub-block visible, no sequence end) carries no compare or select at all; the edge body (the
+//     diagonal sub-block, the sequence's last tile) masks with selects against per-lane limits.
 #include "bp_common.h"
 #include "bp_dma.h"
 #include "bp_kernels.h"
@@ -33,60 +46,87 @@ namespace bp {
 
 namespace {
 
-template <int KD, int NV>
+template <int KD>
 struct BwdCfg {
     static constexpr int NT = 256, NWAVE = 4, NSTAGE = 2, BT = 64;   // BT: rows of a streamed tile
-    static constexpr int RROW = KD <= 4 ? 128 : 256;                 // row-image pitch (b128 reads)
-    static constexpr int RSLOTS = RROW / 16;
-    static constexpr int TROW = NV * 64;                             // transposed-read image pitch
-    static constexpr int TCH = NV * 4;
-    static constexpr int RTILE = BT * RROW;
-    static constexpr int TTILE = BT * TROW;
-    static constexpr int R_DMA = RTILE / 1024 / NWAVE;               // DMA instructions per wave
-    static constexpr int T_DMA = TTILE / 1024 / NWAVE;
-    static constexpr int R_ROWS_PER_DMA = 1024 / RROW;
+    static constexpr int NV = (KD + 1) / 2;                          // 32-wide blocks of the head dimension
+    static constexpr int ROW = KD <= 4 ? 128 : 256;                  // bytes per tile row in LDS (power of two)
+    static constexpr int SLOTS = ROW / 16;
+    static constexpr int TILE = BT * ROW;
+    static constexpr int DMA = TILE / 1024 / NWAVE;                  // 1-KiB pieces per wave per tile: 2 or 4
+    static constexpr int ROWS_PER_DMA = 1024 / ROW;
 };
 
-// per-lane DMA descriptor (tile row, first column) of one 1-KiB piece of a row image /
-// transposed-read image
-template <class C>
-BP_DEV void r_piece(int wave, int lane, int j, int &row, int &col) {
-    row = (wave * C::R_DMA + j) * C::R_ROWS_PER_DMA + lane / C::RSLOTS;
-    col = ((lane % C::RSLOTS) ^ k_swz<C::RROW>(row)) * 8;
+// Slot swizzle of the single LDS image (see the header).  Row bits 0..3 only: +16 / +32 rows keep a lane's swizzle.
+//   ROW = 128 (two rows per 256-byte bank line): rows of equal parity r = 2j + p need 8 different slots -> a
+//     bijection of j; a transposing pass reads rows 4m .. 4m+3, of which 4m and 4m+2 share a bank half -> bit 2 of
+//     the swizzle (the 64-byte chunk select) must differ between j = 2m and 2m + 1: swz = (j & 1) << 2 | j >> 1.
+//   ROW = 256 (one row per bank line): 16 rows need 16 different slots, 4 consecutive rows 4 different quarters:
+//     swz = (r & 3) << 2 | (r >> 2) & 3.
+template <int ROW> BP_DEV int bwd_swz(int row) {
+    return ROW == 128 ? ((((row >> 1) & 1) << 2) | ((row >> 2) & 3)) : (((row & 3) << 2) | ((row >> 2) & 3));
 }
-template <class C, int NV>
-BP_DEV void t_piece(int wave, int lane, int j, int &row, int &col) {
-    const int c = (wave * C::T_DMA + j) * 64 + lane;
-    row = c / C::TCH;
-    const int stored = c - row * C::TCH;
-    int c64 = stored >> 2;
-    if (NV == 2) c64 ^= (row >> 1) & 1;
-    if (NV == 4) c64 ^= row & 3;
-    col = ((c64 << 2) | (stored & 3)) * 8;
+
+// per-lane source descriptor of 1-KiB piece j of a tile: tile row and first element column of the lane's 16 bytes
+template <class C> BP_DEV void piece(int wave, int lane, int j, int &row, int &col) {
+    row = (wave * C::DMA + j) * C::ROWS_PER_DMA + lane / C::SLOTS;
+    col = ((lane % C::SLOTS) ^ bwd_swz<C::ROW>(row)) * 8;
+}
+
+// lane offsets of the two read patterns
+template <class C> BP_DEV int row_read_off(int l31, int hh, int s) {
+    return l31 * C::ROW + (((2 * s + hh) ^ bwd_swz<C::ROW>(l31)) * 16);
+}
+// transposing read of head-dim block n, rows (4 hh + quad row) + 8 h: see lds_read_tr16_8B
+template <class C> BP_DEV int tr_read_off(int lane, int n, int h) {
+    const int row = 4 * (lane >> 5) + ((lane & 15) >> 2) + 8 * h;
+    const int slot = 4 * n + ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1);
+    return row * C::ROW + ((slot ^ bwd_swz<C::ROW>(row)) * 16) + (lane & 1) * 8;
+}
+
+struct SeqInfo {
+    int seq_q, seq_k;
+    int64_t q_row0, k_row0;
+};
+BP_DEV SeqInfo seq_info(const FlashBwdParams &p, int batch) {
+    SeqInfo s;
+    if (p.cu_q != nullptr) {
+        const int a = p.cu_q[batch], b = p.cu_q[batch + 1];
+        const int c = p.cu_k[batch], d = p.cu_k[batch + 1];
+        s.seq_q = b - a; s.seq_k = d - c; s.q_row0 = a; s.k_row0 = c;
+    } else {
+        s.seq_q = p.max_sq; s.seq_k = p.max_sk;
+        s.q_row0 = (int64_t)batch * p.max_sq; s.k_row0 = (int64_t)batch * p.max_sk;
+    }
+    return s;
 }
 
 }  // namespace
 
+// statistics workspace: per (batch, head) two rows of lse_stride floats: -D, then -L / scale
+BP_DEV float *stats_row(const FlashBwdParams &p, int batch, int head) {
+    return p.dsum + ((int64_t)batch * p.h + head) * 2 * p.lse_stride;
+}
+
 // =====================================================================================================
 // dK, dV
 // =====================================================================================================
-template <int KD, int NV>
+template <int KD>
 struct DkdvCfg {
-    using C = BwdCfg<KD, NV>;
-    // stage = Q row image | Q transposed-read image | dO row image | dO transposed-read image | stats
-    static constexpr int STATS = 4 * 512;   // per wave: 64 x lse2, 64 x D (fp32)
-    static constexpr int STAGE = 2 * C::RTILE + 2 * C::TTILE + STATS;
+    using C = BwdCfg<KD>;
+    // stage = Q image | dO image | 64 x -D | 64 x -L/scale
+    static constexpr int Q_OFF = 0, DO_OFF = C::TILE, D_OFF = 2 * C::TILE, L_OFF = 2 * C::TILE + 256;
+    static constexpr int STAGE = 2 * C::TILE + 512;
     static constexpr int SMEM = C::NSTAGE * STAGE;
 };
 
 // one 128-key tile `kt` of (sample, head) `bh`
-template <class ET, int KD, int NV, bool DROP>
+template <class ET, int KD, bool FULLD, bool DROP>
 BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32_t lds0, const int bh, const int kt) {
-    using C = BwdCfg<KD, NV>;
+    using C = BwdCfg<KD>;
+    using G = DkdvCfg<KD>;
     using E = Elem<ET>;
-    constexpr int STATS = DkdvCfg<KD, NV>::STATS;
-    constexpr int STAGE = DkdvCfg<KD, NV>::STAGE;
-    constexpr int DMA_PER_STAGE = 2 * C::R_DMA + 2 * C::T_DMA + 1;
+    constexpr int NV = C::NV;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -96,25 +136,15 @@ BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32
 
     const int batch = bh / p.h;
     const int head = bh - batch * p.h;
-
-    int seq_q, seq_k;
-    int64_t q_row0, k_row0;
-    if (p.cu_q != nullptr) {
-        const int a = p.cu_q[batch], b = p.cu_q[batch + 1];
-        const int c = p.cu_k[batch], d = p.cu_k[batch + 1];
-        seq_q = b - a; seq_k = d - c; q_row0 = a; k_row0 = c;
-    } else {
-        seq_q = p.max_sq; seq_k = p.max_sk;
-        q_row0 = (int64_t)batch * p.max_sq; k_row0 = (int64_t)batch * p.max_sk;
-    }
+    const SeqInfo si = seq_info(p, batch);
+    const int seq_q = si.seq_q, seq_k = si.seq_k;
     if (kt * 128 >= seq_k) return;
 
-    const uint16_t *qg = reinterpret_cast<const uint16_t *>(p.q) + q_row0 * p.q_rs + (int64_t)head * p.q_hs;
-    const uint16_t *dog = reinterpret_cast<const uint16_t *>(p.dout) + q_row0 * p.do_rs + (int64_t)head * p.do_hs;
-    const uint16_t *kg = reinterpret_cast<const uint16_t *>(p.k) + k_row0 * p.k_rs + (int64_t)head * p.k_hs;
-    const uint16_t *vg = reinterpret_cast<const uint16_t *>(p.v) + k_row0 * p.v_rs + (int64_t)head * p.v_hs;
-    const float *lse_g = p.lse + ((int64_t)batch * p.h + head) * p.lse_stride;
-    const float *dsum_g = p.dsum + ((int64_t)batch * p.h + head) * p.lse_stride;
+    const uint16_t *qg = reinterpret_cast<const uint16_t *>(p.q) + si.q_row0 * p.q_rs + (int64_t)head * p.q_hs;
+    const uint16_t *dog = reinterpret_cast<const uint16_t *>(p.dout) + si.q_row0 * p.do_rs + (int64_t)head * p.do_hs;
+    const uint16_t *kg = reinterpret_cast<const uint16_t *>(p.k) + si.k_row0 * p.k_rs + (int64_t)head * p.k_hs;
+    const uint16_t *vg = reinterpret_cast<const uint16_t *>(p.v) + si.k_row0 * p.v_rs + (int64_t)head * p.v_hs;
+    const float *stats_g = stats_row(p, batch, head);
 
     const int key0 = kt * 128 + wave * 32;        // first key of this wave
     const int my_key = key0 + l31;
@@ -124,10 +154,22 @@ BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32
     // query tiles that can see this workgroup's keys: causal -> queries >= first key
     const int qt_begin = p.causal ? (kt * 128) / C::BT : 0;
     const int nqt = (seq_q + C::BT - 1) / C::BT;
+    if (qt_begin >= nqt) {
+        // no query sees these keys (causal, seq_k > seq_q): their gradients are zero
+        if (wave_has_keys && my_key < seq_k) {
+            uint16_t *dkg = reinterpret_cast<uint16_t *>(p.dk) + (si.k_row0 + my_key) * p.dk_rs + (int64_t)head * p.dk_hs;
+            uint16_t *dvg = reinterpret_cast<uint16_t *>(p.dv) + (si.k_row0 + my_key) * p.dv_rs + (int64_t)head * p.dv_hs;
+            for (int d0 = 4 * hh; d0 < p.d; d0 += 8) {
+                *reinterpret_cast<u32x2 *>(dkg + d0) = u32x2{0u, 0u};
+                *reinterpret_cast<u32x2 *>(dvg + d0) = u32x2{0u, 0u};
+            }
+        }
+        return;
+    }
 
-    if (p.d * 2 != C::RROW) {   // pad slots of the row images must read as 0
+    if (!FULLD) {   // pad slots of the images must read as 0 (they meet zero K / V columns in the MFMAs)
         const u32x4 z = {0u, 0u, 0u, 0u};
-        for (int off = tid * 16; off < C::NSTAGE * STAGE; off += C::NT * 16) lds_write_16B(smem, off, z);
+        for (int off = tid * 16; off < G::SMEM; off += C::NT * 16) lds_write_16B(smem, off, z);
         __syncthreads();
     }
 
@@ -142,7 +184,7 @@ BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32
         for (int s = 0; s < KD; ++s) {
             const int col = 16 * s + 8 * hh;
             u32x4 a = {0u, 0u, 0u, 0u}, b = {0u, 0u, 0u, 0u};
-            if (col < p.d) {
+            if (FULLD || col < p.d) {
                 a = ld_global_16B(kg + (int64_t)key * p.k_rs + col);
                 b = ld_global_16B(vg + (int64_t)key * p.v_rs + col);
             }
@@ -153,37 +195,42 @@ BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32
         for (int s = 0; s < KD; ++s) { settle(kf[s]); settle(vf[s]); }   // see bp_common.h: no vmcnt(0) in the loop
     }
 
-    // ---- DMA descriptors -----------------------------------------------------------------------------
-    int rr[C::R_DMA], rc[C::R_DMA], tr[C::T_DMA], tc[C::T_DMA];
+    // ---- DMA: constant per-lane byte offsets, scalar tile pointers --------------------------------------
+    const int qt_partial = (seq_q % C::BT) != 0 ? seq_q / C::BT : -1;
+    const int last_row = seq_q - 1 - (seq_q / C::BT) * C::BT;
+    uint32_t q_voff[C::DMA], do_voff[C::DMA], q_voff_p[C::DMA], do_voff_p[C::DMA];
+    bool piece_live[C::DMA];
 #pragma unroll
-    for (int j = 0; j < C::R_DMA; ++j) r_piece<C>(wave, lane, j, rr[j], rc[j]);
-#pragma unroll
-    for (int j = 0; j < C::T_DMA; ++j) t_piece<C, NV>(wave, lane, j, tr[j], tc[j]);
+    for (int j = 0; j < C::DMA; ++j) {
+        int row, col;
+        piece<C>(wave, lane, j, row, col);
+        piece_live[j] = FULLD || col < p.d;
+        q_voff[j] = (uint32_t)(row * p.q_rs + col) * 2u;
+        do_voff[j] = (uint32_t)(row * p.do_rs + col) * 2u;
+        q_voff_p[j] = (uint32_t)(min(row, last_row) * p.q_rs + col) * 2u;
+        do_voff_p[j] = (uint32_t)(min(row, last_row) * p.do_rs + col) * 2u;
+    }
+    const int64_t q_tile_stride = (int64_t)C::BT * p.q_rs, do_tile_stride = (int64_t)C::BT * p.do_rs;
+    const uint16_t *qt_ptr = qg + (int64_t)qt_begin * q_tile_stride;     // tile of the NEXT issue
+    const uint16_t *dot_ptr = dog + (int64_t)qt_begin * do_tile_stride;
     auto issue = [&](int qt) {
-        const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + ((qt - qt_begin) % C::NSTAGE) * STAGE);
-        const int row_base = qt * C::BT;
+        const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + ((qt - qt_begin) & 1) * G::STAGE);
+        const bool partial = qt == qt_partial;
 #pragma unroll
-        for (int j = 0; j < C::R_DMA; ++j) {
-            const int64_t row = min(row_base + rr[j], seq_q - 1);
-            if (rc[j] < p.d) {
-                dma16_d(qg + row * p.q_rs + rc[j], st + (wave * C::R_DMA + j) * 1024);
-                dma16_d(dog + row * p.do_rs + rc[j], st + C::RTILE + C::TTILE + (wave * C::R_DMA + j) * 1024);
+        for (int j = 0; j < C::DMA; ++j)
+            if (piece_live[j]) {
+                dma16_s(qt_ptr, partial ? q_voff_p[j] : q_voff[j],
+                        __builtin_amdgcn_readfirstlane(st + G::Q_OFF + (wave * C::DMA + j) * 1024));
+                dma16_s(dot_ptr, partial ? do_voff_p[j] : do_voff[j],
+                        __builtin_amdgcn_readfirstlane(st + G::DO_OFF + (wave * C::DMA + j) * 1024));
             }
+        // the tile's 64 x -D (wave 0) and 64 x -L/scale (wave 1); rows past the sequence: anything, they are masked
+        if (wave < 2) {
+            const float *src = stats_g + wave * p.lse_stride + min(qt * C::BT + lane, (int)p.lse_stride - 1);
+            dma4(src, st + G::D_OFF + wave * 256);
         }
-#pragma unroll
-        for (int j = 0; j < C::T_DMA; ++j) {
-            const int64_t row = min(row_base + tr[j], seq_q - 1);
-            if (tc[j] < p.d) {
-                dma16_d(qg + row * p.q_rs + tc[j], st + C::RTILE + (wave * C::T_DMA + j) * 1024);
-                dma16_d(dog + row * p.do_rs + tc[j], st + 2 * C::RTILE + C::TTILE + (wave * C::T_DMA + j) * 1024);
-            }
-        }
-        // row statistics of the 64 queries (private copy per wave): lanes 0..15 L, 16..31 D
-        if (lane < 32) {
-            const int i4 = (lane & 15) * 4;
-            const float *src = (lane < 16 ? lse_g : dsum_g) + min(row_base + i4, (int)p.lse_stride - 4);
-            dma16_d(reinterpret_cast<const uint16_t *>(src), st + 2 * C::RTILE + 2 * C::TTILE + wave * 512);
-        }
+        qt_ptr += q_tile_stride;
+        dot_ptr += do_tile_stride;
     };
 
     f32x16 dk[NV], dv[NV];
@@ -192,97 +239,147 @@ BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[n][r] = 0.f; dv[n][r] = 0.f; }
 
-    int r_read_off[KD];   // A operand rows (lane = query l31): slot 2s+hh swizzled
+    int r_off[KD];   // A operand rows (lane = query l31)
 #pragma unroll
-    for (int s = 0; s < KD; ++s) r_read_off[s] = l31 * C::RROW + (((2 * s + hh) ^ k_swz<C::RROW>(l31)) * 16);
-    int t_read_off[NV];   // transposed-read operand: d block n, 4 consecutive rows
-    {
-        const int row_lane = 4 * hh + ((lane & 15) >> 2);
-        const int ch_lane = ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1);
+    for (int s = 0; s < KD; ++s) r_off[s] = row_read_off<C>(l31, hh, s);
+    int t_off[NV][2];   // transposing reads: head-dim block n, rows +0 / +8
 #pragma unroll
-        for (int n = 0; n < NV; ++n) t_read_off[n] = v_lds_off<NV>(row_lane, n * 4 + ch_lane) + (lane & 1) * 8;
+    for (int n = 0; n < NV; ++n) {
+        t_off[n][0] = tr_read_off<C>(lane, n, 0);
+        t_off[n][1] = tr_read_off<C>(lane, n, 1);
     }
 
-    if (qt_begin < nqt) issue(qt_begin);
-    // one ring step; SLOT = ring slot as a compile-time constant (loop unrolled by the ring depth: static LDS offsets)
-    auto ring_step = [&](int qt, auto SLOT) {
-        constexpr int kSlot = decltype(SLOT)::value;
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (qt + 1 < nqt) issue(qt + 1);
-        if (!wave_has_keys) return;
-        const char *st = smem + kSlot * STAGE;
-        const char *q_r = st, *q_t = st + C::RTILE;
-        const char *do_r = st + C::RTILE + C::TTILE, *do_t = st + 2 * C::RTILE + C::TTILE;
-        const char *stats = st + 2 * C::RTILE + 2 * C::TTILE + wave * 512;
+    // One 32-query sub-block `qb` of the tile in `st`.  EDGE: mask what is not a (query, key) pair of the problem.
+    auto sub_block = [&](const char *st, int qt, int qb, auto EDGE) {
+        constexpr bool kEdge = decltype(EDGE)::value;
+        const int qbase = qt * C::BT + qb * 32;          // first query of this sub-block
+        // ---- S = Q K^T - L/scale and dP = dO V^T - D : rows = queries (registers), column = my key; the row
+        //      constants are the accumulators' initial values
+        f32x16 s_, dp;
+        float dneg[DROP ? 16 : 1];
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            const int qbase = qt * C::BT + qb * 32;          // first query of this 32-row sub-block
-            if (qbase >= seq_q) continue;
-            if (p.causal && qbase + 31 < key0) continue;     // every query is before my first key
-            // ---- S = Q K^T and dP = dO V^T : rows = queries (registers), column = my key ---------------
-            f32x16 s_, dp;
+        for (int g = 0; g < 4; ++g) {
+            const u32x4 l4 = lds_read_16B(st, G::L_OFF + (qb * 32 + 8 * g + 4 * hh) * 4);
+            const u32x4 d4 = lds_read_16B(st, G::D_OFF + (qb * 32 + 8 * g + 4 * hh) * 4);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s_[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-            for (int s = 0; s < KD; ++s) {
-                const u32x4 a = lds_read_16B(q_r, r_read_off[s] + qb * 32 * C::RROW);
-                s_ = E::mfma(a, kf[s], s_);
-                const u32x4 b = lds_read_16B(do_r, r_read_off[s] + qb * 32 * C::RROW);
-                dp = E::mfma(b, vf[s], dp);
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t lw = l4[i], dw = d4[i];   // by-value copies (bp_common.h, as_f32)
+                s_[4 * g + i] = as_f32(lw);
+                if (DROP) { dp[4 * g + i] = 0.f; dneg[4 * g + i] = as_f32(dw); }
+                else dp[4 * g + i] = as_f32(dw);
             }
-            // ---- P = exp2(S*c - L*log2e), dS = P (dP - D) ------------------------------------------------
-            u32x4 pf[2], dsf[2];
-            uint32_t keep = 0xffffu;   // bit 4g+i: query qbase + 8g + 4hh + i keeps my key
-            if (DROP) keep = dropout_keep_collane(rng, p.drop_thr, (uint32_t)qbase, (uint32_t)my_key, hh);
+        }
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const u32x4 l4 = lds_read_16B(stats, (qb * 32 + 8 * g + 4 * hh) * 4);
-                const u32x4 d4 = lds_read_16B(stats, 256 + (qb * 32 + 8 * g + 4 * hh) * 4);
-                float pe[4], de[4];
+        for (int s = 0; s < KD; ++s) {
+            const u32x4 a = lds_read_16B(st, G::Q_OFF + r_off[s] + qb * 32 * C::ROW);
+            s_ = E::mfma(a, kf[s], s_);
+            const u32x4 b = lds_read_16B(st, G::DO_OFF + r_off[s] + qb * 32 * C::ROW);
+            dp = E::mfma(b, vf[s], dp);
+        }
+        // ---- P = exp2((S - L/scale) c), dS = P (dP - D) ----------------------------------------------------
+        uint32_t keep = 0xffffu;   // bit 4g+i: query qbase + 8g + 4hh + i keeps my key
+        if (DROP) keep = dropout_keep_collane(rng, p.drop_thr, (uint32_t)qbase, (uint32_t)my_key, hh);
+        // register r holds query qbase + (r & 3) + 8 (r >> 2) + 4 hh: dead iff that is before my key (causal), past
+        // the sequence, or my key does not exist -> two per-lane limits against compile-time constants
+        int lim_lo = 0, lim_hi = 64;
+        if (kEdge) {
+            lim_lo = p.causal ? my_key - qbase - 4 * hh : 0;
+            lim_hi = seq_q - qbase - 4 * hh;
+            if (my_key >= seq_k) lim_hi = 0;
+        }
+        u32x4 pf[2], dsf[2];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = 4 * g + i;
-                    const int q = qbase + 8 * g + 4 * hh + i;
-                    float pv = fast_exp2(fmaf(s_[r], c2, -as_f32(l4[i]) * kLog2e));
-                    const bool dead = q >= seq_q || my_key >= seq_k || (p.causal && my_key > q);
-                    // selects, not multiplies: L / D of rows past the sequence are uninitialised (maybe NaN)
-                    float z = 1.f;
-                    if (DROP) z = ((keep >> r) & 1u) ? p.drop_scale : 0.f;
-                    pe[i] = dead ? 0.f : (DROP ? pv * z : pv);
-                    de[i] = dead ? 0.f : pv * ((DROP ? dp[r] * z : dp[r]) - as_f32(d4[i]));
+        for (int g = 0; g < 4; ++g) {
+            float pe[4], de[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * g + i;
+                const float pv = fast_exp2(s_[r] * c2);
+                if (DROP) {
+                    const float z = ((keep >> r) & 1u) ? p.drop_scale : 0.f;
+                    pe[i] = pv * z;
+                    de[i] = pv * fmaf(dp[r], z, dneg[r]);
+                } else {
+                    pe[i] = pv;
+                    de[i] = pv * dp[r];
                 }
-                // regs 8*ks .. 8*ks+7 are the B operand of K-step ks (queries {0..3, 8..11} + 4hh + 16ks)
-                pf[g >> 1][(g & 1) * 2 + 0] = E::pack2(pe[0], pe[1]);
-                pf[g >> 1][(g & 1) * 2 + 1] = E::pack2(pe[2], pe[3]);
-                dsf[g >> 1][(g & 1) * 2 + 0] = E::pack2(de[0], de[1]);
-                dsf[g >> 1][(g & 1) * 2 + 1] = E::pack2(de[2], de[3]);
+                if (kEdge) {
+                    // selects, not multiplies: the statistics of rows past the sequence are uninitialised (maybe NaN)
+                    const int c = i + 8 * g;
+                    const bool dead = c < lim_lo || c >= lim_hi;
+                    pe[i] = dead ? 0.f : pe[i];
+                    de[i] = dead ? 0.f : de[i];
+                }
             }
-            // ---- dV^T += dO^T P ; dK^T += Q^T dS   (contraction over the 32 queries) -------------------
+            // regs 8*ks .. 8*ks+7 are the B operand of K-step ks (queries {0..3, 8..11} + 4hh + 16ks)
+            pf[g >> 1][(g & 1) * 2 + 0] = E::pack2(pe[0], pe[1]);
+            pf[g >> 1][(g & 1) * 2 + 1] = E::pack2(pe[2], pe[3]);
+            dsf[g >> 1][(g & 1) * 2 + 0] = E::pack2(de[0], de[1]);
+            dsf[g >> 1][(g & 1) * 2 + 1] = E::pack2(de[2], de[3]);
+        }
+        // ---- dV^T += dO^T P ; dK^T += Q^T dS   (contraction over the 32 queries) -------------------
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int rows = (qb * 32 + ks * 16) * C::TROW;
+        for (int ks = 0; ks < 2; ++ks) {
+            const int rows = (qb * 32 + ks * 16) * C::ROW;
 #pragma unroll
-                for (int n = 0; n < NV; ++n) {
-                    const u32x2 lo = lds_read_tr16_8B(do_t, t_read_off[n] + rows);
-                    const u32x2 hi = lds_read_tr16_8B(do_t, t_read_off[n] + rows + 8 * C::TROW);
-                    dv[n] = E::mfma(u32x4{lo[0], lo[1], hi[0], hi[1]}, pf[ks], dv[n]);
-                    const u32x2 lo2 = lds_read_tr16_8B(q_t, t_read_off[n] + rows);
-                    const u32x2 hi2 = lds_read_tr16_8B(q_t, t_read_off[n] + rows + 8 * C::TROW);
-                    dk[n] = E::mfma(u32x4{lo2[0], lo2[1], hi2[0], hi2[1]}, dsf[ks], dk[n]);
-                }
+            for (int n = 0; n < NV; ++n) {
+                const u32x2 lo = lds_read_tr16_8B(st, G::DO_OFF + t_off[n][0] + rows);
+                const u32x2 hi = lds_read_tr16_8B(st, G::DO_OFF + t_off[n][1] + rows);
+                dv[n] = E::mfma(u32x4{lo[0], lo[1], hi[0], hi[1]}, pf[ks], dv[n]);
+                const u32x2 lo2 = lds_read_tr16_8B(st, G::Q_OFF + t_off[n][0] + rows);
+                const u32x2 hi2 = lds_read_tr16_8B(st, G::Q_OFF + t_off[n][1] + rows);
+                dk[n] = E::mfma(u32x4{lo2[0], lo2[1], hi2[0], hi2[1]}, dsf[ks], dk[n]);
             }
         }
     };
-    static_assert(C::NSTAGE == 2, "unrolled by the 2-slot ring");
-    for (int qt = qt_begin; qt < nqt; qt += 2) {
-        ring_step(qt, std::integral_constant<int, 0>{});
-        if (qt + 1 < nqt) ring_step(qt + 1, std::integral_constant<int, 1>{});
+
+    // ring step: my share of tile qt has landed, everybody's after the barrier; refill the other slot
+    auto step_begin = [&](int qt) -> const char * {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (qt + 1 < nqt) issue(qt + 1);
+        return smem + ((qt - qt_begin) & 1) * G::STAGE;
+    };
+    // a tile near the diagonal or the sequence end: per sub-block skip / masked body
+    auto edge_tile = [&](int qt) {
+        const char *st = step_begin(qt);
+        if (!wave_has_keys) return;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const int qbase = qt * C::BT + qb * 32;
+            if (qbase >= seq_q) continue;
+            if (p.causal && qbase + 31 < key0) continue;     // every query is before my first key
+            sub_block(st, qt, qb, std::true_type{});
+        }
+    };
+    auto clean_tile = [&](int qt) {
+        const char *st = step_begin(qt);
+        sub_block(st, qt, 0, std::false_type{});
+        sub_block(st, qt, 1, std::false_type{});
+    };
+
+    // Three sequential loops, one body each (an if/else join of the 2 x NV accumulator sets inside ONE loop makes the
+    // register allocator copy or spill them, DESIGN.md "compiler findings"):
+    //   edge tiles up to the one that holds my diagonal | clean tiles | the sequence's last, partial tile(s).
+    // A wave without keys, or whose keys run past the sequence, takes the edge body throughout.
+    int clean_begin = nqt, clean_end = nqt;
+    if (wave_has_keys && key0 + 32 <= seq_k) {
+        // first tile whose every query is at or after my last key (key0 is a multiple of 32) ... last full tile
+        clean_begin = p.causal ? max(qt_begin, (key0 + 31 + C::BT) / C::BT) : qt_begin;
+        clean_end = seq_q / C::BT;
     }
+    clean_begin = min(clean_begin, nqt);
+    clean_end = min(max(clean_end, clean_begin), nqt);
+
+    issue(qt_begin);
+    int qt = qt_begin;
+    for (; qt < clean_begin; ++qt) edge_tile(qt);
+    for (; qt < clean_end; ++qt) clean_tile(qt);
+    for (; qt < nqt; ++qt) edge_tile(qt);
 
     if (!wave_has_keys || my_key >= seq_k) return;
-    uint16_t *dkg = reinterpret_cast<uint16_t *>(p.dk) + (k_row0 + my_key) * p.dk_rs + (int64_t)head * p.dk_hs;
-    uint16_t *dvg = reinterpret_cast<uint16_t *>(p.dv) + (k_row0 + my_key) * p.dv_rs + (int64_t)head * p.dv_hs;
+    uint16_t *dkg = reinterpret_cast<uint16_t *>(p.dk) + (si.k_row0 + my_key) * p.dk_rs + (int64_t)head * p.dk_hs;
+    uint16_t *dvg = reinterpret_cast<uint16_t *>(p.dv) + (si.k_row0 + my_key) * p.dv_rs + (int64_t)head * p.dv_hs;
 #pragma unroll
     for (int n = 0; n < NV; ++n)
 #pragma unroll
@@ -302,12 +399,13 @@ BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32
 // dQ
 // =====================================================================================================
 // one 128-query tile `qt` of (sample, head) `bh`
-template <class ET, int KD, int NV, bool DROP>
+template <class ET, int KD, bool FULLD, bool DROP>
 BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t lds0, const int bh, const int qt) {
-    using C = BwdCfg<KD, NV>;
+    using C = BwdCfg<KD>;
     using E = Elem<ET>;
-    // stage = K row image | K transposed-read image | V row image
-    constexpr int STAGE = 2 * C::RTILE + C::TTILE;
+    constexpr int NV = C::NV;
+    // stage = K image | V image
+    constexpr int K_OFF = 0, V_OFF = C::TILE, STAGE = 2 * C::TILE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -317,23 +415,14 @@ BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t
 
     const int batch = bh / p.h;
     const int head = bh - batch * p.h;
-
-    int seq_q, seq_k;
-    int64_t q_row0, k_row0;
-    if (p.cu_q != nullptr) {
-        const int a = p.cu_q[batch], b = p.cu_q[batch + 1];
-        const int c = p.cu_k[batch], d = p.cu_k[batch + 1];
-        seq_q = b - a; seq_k = d - c; q_row0 = a; k_row0 = c;
-    } else {
-        seq_q = p.max_sq; seq_k = p.max_sk;
-        q_row0 = (int64_t)batch * p.max_sq; k_row0 = (int64_t)batch * p.max_sk;
-    }
+    const SeqInfo si = seq_info(p, batch);
+    const int seq_q = si.seq_q, seq_k = si.seq_k;
     if (qt * 128 >= seq_q) return;
 
-    const uint16_t *qg = reinterpret_cast<const uint16_t *>(p.q) + q_row0 * p.q_rs + (int64_t)head * p.q_hs;
-    const uint16_t *dog = reinterpret_cast<const uint16_t *>(p.dout) + q_row0 * p.do_rs + (int64_t)head * p.do_hs;
-    const uint16_t *kg = reinterpret_cast<const uint16_t *>(p.k) + k_row0 * p.k_rs + (int64_t)head * p.k_hs;
-    const uint16_t *vg = reinterpret_cast<const uint16_t *>(p.v) + k_row0 * p.v_rs + (int64_t)head * p.v_hs;
+    const uint16_t *qg = reinterpret_cast<const uint16_t *>(p.q) + si.q_row0 * p.q_rs + (int64_t)head * p.q_hs;
+    const uint16_t *dog = reinterpret_cast<const uint16_t *>(p.dout) + si.q_row0 * p.do_rs + (int64_t)head * p.do_hs;
+    const uint16_t *kg = reinterpret_cast<const uint16_t *>(p.k) + si.k_row0 * p.k_rs + (int64_t)head * p.k_hs;
+    const uint16_t *vg = reinterpret_cast<const uint16_t *>(p.v) + si.k_row0 * p.v_rs + (int64_t)head * p.v_hs;
 
     int k_end = seq_k;
     if (p.causal) k_end = min(seq_k, qt * 128 + 128);
@@ -344,7 +433,7 @@ BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t
     const bool wave_has_rows = q0 < seq_q;
     const float c2 = p.scale * kLog2e;
 
-    if (p.d * 2 != C::RROW) {
+    if (!FULLD) {
         const u32x4 z = {0u, 0u, 0u, 0u};
         for (int off = tid * 16; off < C::NSTAGE * STAGE; off += C::NT * 16) lds_write_16B(smem, off, z);
         __syncthreads();
@@ -354,16 +443,16 @@ BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t
     if (DROP) rng = dropout_stream(p.rng_state, (uint32_t)bh);
 
     u32x4 qf[KD], dof[KD];
-    float lse2 = 0.f, dsum = 0.f;
+    float lneg = 0.f, dneg = 0.f;   // -L / scale, -D of my row
     {
         const int q = min(my_q, seq_q - 1);
-        const uint16_t *og = reinterpret_cast<const uint16_t *>(p.out) + (q_row0 + q) * p.o_rs + (int64_t)head * p.o_hs;
+        const uint16_t *og = reinterpret_cast<const uint16_t *>(p.out) + (si.q_row0 + q) * p.o_rs + (int64_t)head * p.o_hs;
         float part = 0.f;   // my 8*KD columns of dO . O
 #pragma unroll
         for (int s = 0; s < KD; ++s) {
             const int col = 16 * s + 8 * hh;
             u32x4 a = {0u, 0u, 0u, 0u}, b = {0u, 0u, 0u, 0u}, o = {0u, 0u, 0u, 0u};
-            if (col < p.d) {
+            if (FULLD || col < p.d) {
                 a = ld_global_16B(qg + (int64_t)q * p.q_rs + col);
                 b = ld_global_16B(dog + (int64_t)q * p.do_rs + col);
                 o = ld_global_16B(og + col);
@@ -377,35 +466,54 @@ BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t
                 part = fmaf(E::hi_f32(bw), E::hi_f32(ow), part);
             }
         }
-        const int64_t so = ((int64_t)batch * p.h + head) * p.lse_stride + q;
-        lse2 = p.lse[so] * kLog2e;
-        dsum = xhalf_sum(part);   // the two half-waves hold the two 8-column halves of every 16
-        if (hh == 0 && wave_has_rows && my_q < seq_q) p.dsum[so] = dsum;
+        const float lse = p.lse[((int64_t)batch * p.h + head) * p.lse_stride + q];
+        // (a row without keys has L = -inf and meets no key tile: any finite stand-in will do)
+        lneg = lse == -INFINITY ? 0.f : -lse / p.scale;
+        dneg = -xhalf_sum(part);   // the two half-waves hold the two 8-column halves of every 16
+        if (hh == 0 && wave_has_rows && my_q < seq_q) {
+            float *st = stats_row(p, batch, head);
+            st[q] = dneg;
+            st[p.lse_stride + q] = lneg;
+        }
 #pragma unroll
         for (int s = 0; s < KD; ++s) { settle(qf[s]); settle(dof[s]); }
-        settle(lse2); settle(dsum);
+        settle(lneg); settle(dneg);
     }
+    // the row constants as MFMA C operands of the first K-step (never written: the chains start from them)
+    f32x16 c_l, c_d;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { c_l[r] = lneg; c_d[r] = DROP ? 0.f : dneg; }
 
-    int rr[C::R_DMA], rc[C::R_DMA], tr[C::T_DMA], tc[C::T_DMA];
+    // ---- DMA -----------------------------------------------------------------------------------------------
+    const int kb_partial = (seq_k % C::BT) != 0 ? seq_k / C::BT : -1;
+    const int last_row = seq_k - 1 - (seq_k / C::BT) * C::BT;
+    uint32_t k_voff[C::DMA], v_voff[C::DMA], k_voff_p[C::DMA], v_voff_p[C::DMA];
+    bool piece_live[C::DMA];
 #pragma unroll
-    for (int j = 0; j < C::R_DMA; ++j) r_piece<C>(wave, lane, j, rr[j], rc[j]);
-#pragma unroll
-    for (int j = 0; j < C::T_DMA; ++j) t_piece<C, NV>(wave, lane, j, tr[j], tc[j]);
+    for (int j = 0; j < C::DMA; ++j) {
+        int row, col;
+        piece<C>(wave, lane, j, row, col);
+        piece_live[j] = FULLD || col < p.d;
+        k_voff[j] = (uint32_t)(row * p.k_rs + col) * 2u;
+        v_voff[j] = (uint32_t)(row * p.v_rs + col) * 2u;
+        k_voff_p[j] = (uint32_t)(min(row, last_row) * p.k_rs + col) * 2u;
+        v_voff_p[j] = (uint32_t)(min(row, last_row) * p.v_rs + col) * 2u;
+    }
+    const int64_t k_tile_stride = (int64_t)C::BT * p.k_rs, v_tile_stride = (int64_t)C::BT * p.v_rs;
+    const uint16_t *kt_ptr = kg, *vt_ptr = vg;
     auto issue = [&](int kb) {
-        const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + (kb % C::NSTAGE) * STAGE);
+        const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + (kb & 1) * STAGE);
+        const bool partial = kb == kb_partial;
 #pragma unroll
-        for (int j = 0; j < C::R_DMA; ++j) {
-            const int64_t row = min(kb * C::BT + rr[j], seq_k - 1);
-            if (rc[j] < p.d) {
-                dma16_d(kg + row * p.k_rs + rc[j], st + (wave * C::R_DMA + j) * 1024);
-                dma16_d(vg + row * p.v_rs + rc[j], st + C::RTILE + C::TTILE + (wave * C::R_DMA + j) * 1024);
+        for (int j = 0; j < C::DMA; ++j)
+            if (piece_live[j]) {
+                dma16_s(kt_ptr, partial ? k_voff_p[j] : k_voff[j],
+                        __builtin_amdgcn_readfirstlane(st + K_OFF + (wave * C::DMA + j) * 1024));
+                dma16_s(vt_ptr, partial ? v_voff_p[j] : v_voff[j],
+                        __builtin_amdgcn_readfirstlane(st + V_OFF + (wave * C::DMA + j) * 1024));
             }
-        }
-#pragma unroll
-        for (int j = 0; j < C::T_DMA; ++j) {
-            const int64_t row = min(kb * C::BT + tr[j], seq_k - 1);
-            if (tc[j] < p.d) dma16_d(kg + row * p.k_rs + tc[j], st + C::RTILE + (wave * C::T_DMA + j) * 1024);
-        }
+        kt_ptr += k_tile_stride;
+        vt_ptr += v_tile_stride;
     };
 
     f32x16 dq[NV];
@@ -414,83 +522,102 @@ BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[n][r] = 0.f;
 
-    int r_read_off[KD];
+    int r_off[KD];
 #pragma unroll
-    for (int s = 0; s < KD; ++s) r_read_off[s] = l31 * C::RROW + (((2 * s + hh) ^ k_swz<C::RROW>(l31)) * 16);
-    int t_read_off[NV];
-    {
-        const int row_lane = 4 * hh + ((lane & 15) >> 2);
-        const int ch_lane = ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1);
+    for (int s = 0; s < KD; ++s) r_off[s] = row_read_off<C>(l31, hh, s);
+    int t_off[NV][2];
 #pragma unroll
-        for (int n = 0; n < NV; ++n) t_read_off[n] = v_lds_off<NV>(row_lane, n * 4 + ch_lane) + (lane & 1) * 8;
+    for (int n = 0; n < NV; ++n) {
+        t_off[n][0] = tr_read_off<C>(lane, n, 0);
+        t_off[n][1] = tr_read_off<C>(lane, n, 1);
     }
 
-    if (nkb > 0) issue(0);
-    auto ring_step = [&](int kb, auto SLOT) {
-        constexpr int kSlot = decltype(SLOT)::value;
+    // one 32-key sub-block kk of the tile in `st`
+    auto sub_block = [&](const char *st, int kb, int kk, auto EDGE) {
+        constexpr bool kEdge = decltype(EDGE)::value;
+        const int kbase = kb * C::BT + kk * 32;
+        // S^T = K Q^T - L/scale and dP^T = V dO^T - D : rows = keys (registers), column = my query
+        f32x16 st_ = c_l, dpt = c_d;
+#pragma unroll
+        for (int s = 0; s < KD; ++s) {
+            const u32x4 a = lds_read_16B(st, K_OFF + r_off[s] + kk * 32 * C::ROW);
+            st_ = E::mfma(a, qf[s], st_);
+            const u32x4 b = lds_read_16B(st, V_OFF + r_off[s] + kk * 32 * C::ROW);
+            dpt = E::mfma(b, dof[s], dpt);
+        }
+        uint32_t keep = 0xffffu;   // bit 4g+i: my query keeps key kbase + 8g + 4hh + i
+        if (DROP) keep = dropout_keep_rowlane(rng, p.drop_thr, (uint32_t)my_q, (uint32_t)kbase, hh);
+        // register r holds key kbase + (r & 3) + 8 (r >> 2) + 4 hh: dead iff beyond the last key my row may see
+        int lim = 64;
+        if (kEdge) {
+            int last = seq_k - 1;
+            if (p.causal) last = min(last, my_q);
+            lim = last - kbase - 4 * hh;
+        }
+        u32x4 dsf[2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float de[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * g + i;
+                const float pv = fast_exp2(st_[r] * c2);
+                if (DROP) {
+                    const float z = ((keep >> r) & 1u) ? p.drop_scale : 0.f;
+                    de[i] = pv * fmaf(dpt[r], z, dneg);
+                } else {
+                    de[i] = pv * dpt[r];
+                }
+                if (kEdge) de[i] = (i + 8 * g > lim) ? 0.f : de[i];
+            }
+            dsf[g >> 1][(g & 1) * 2 + 0] = E::pack2(de[0], de[1]);
+            dsf[g >> 1][(g & 1) * 2 + 1] = E::pack2(de[2], de[3]);
+        }
+        // dQ^T += K^T dS^T  (contraction over the 32 keys)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int rows = (kk * 32 + ks * 16) * C::ROW;
+#pragma unroll
+            for (int n = 0; n < NV; ++n) {
+                const u32x2 lo = lds_read_tr16_8B(st, K_OFF + t_off[n][0] + rows);
+                const u32x2 hi = lds_read_tr16_8B(st, K_OFF + t_off[n][1] + rows);
+                dq[n] = E::mfma(u32x4{lo[0], lo[1], hi[0], hi[1]}, dsf[ks], dq[n]);
+            }
+        }
+    };
+
+    auto step_begin = [&](int kb) -> const char * {
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (kb + 1 < nkb) issue(kb + 1);
-        if (!wave_has_rows) return;
-        if (p.causal && kb * C::BT > q0 + 31) return;
-        const char *st = smem + kSlot * STAGE;
-        const char *k_r = st, *k_t = st + C::RTILE, *v_r = st + C::RTILE + C::TTILE;
+        return smem + (kb & 1) * STAGE;
+    };
+    // Which key tiles this wave computes, and which of them the clean body may take: every key exists and every
+    // (query, key) pair of my 32 rows is visible (as in flash_fwd_dma.hip).
+    const int my_nkb = !wave_has_rows ? 0 : p.causal ? min(nkb, (q0 + 31) / C::BT + 1) : nkb;
+    const int my_clean_end = !wave_has_rows ? 0 : p.causal ? min(seq_k / C::BT, (q0 + 1) / C::BT) : seq_k / C::BT;
+
+    if (nkb > 0) issue(0);
+    int kb = 0;
+    for (; kb < min(my_clean_end, nkb); ++kb) {
+        const char *st = step_begin(kb);
+        sub_block(st, kb, 0, std::false_type{});
+        sub_block(st, kb, 1, std::false_type{});
+    }
+    for (; kb < nkb; ++kb) {
+        const char *st = step_begin(kb);
+        if (kb >= my_nkb) continue;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int kbase = kb * C::BT + kk * 32;
             if (kbase >= seq_k) continue;
             if (p.causal && kbase > q0 + 31) continue;
-            // S^T = K Q^T and dP^T = V dO^T : rows = keys (registers), column = my query
-            f32x16 st_, dpt;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { st_[r] = 0.f; dpt[r] = 0.f; }
-#pragma unroll
-            for (int s = 0; s < KD; ++s) {
-                const u32x4 a = lds_read_16B(k_r, r_read_off[s] + kk * 32 * C::RROW);
-                st_ = E::mfma(a, qf[s], st_);
-                const u32x4 b = lds_read_16B(v_r, r_read_off[s] + kk * 32 * C::RROW);
-                dpt = E::mfma(b, dof[s], dpt);
-            }
-            u32x4 dsf[2];
-            uint32_t keep = 0xffffu;   // bit 4g+i: my query keeps key kbase + 8g + 4hh + i
-            if (DROP) keep = dropout_keep_rowlane(rng, p.drop_thr, (uint32_t)my_q, (uint32_t)kbase, hh);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float de[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = 4 * g + i;
-                    const int key = kbase + 8 * g + 4 * hh + i;
-                    const float pv = fast_exp2(fmaf(st_[r], c2, -lse2));
-                    const bool dead = key >= seq_k || (p.causal && key > my_q);
-                    float dpe = dpt[r];
-                    if (DROP) dpe = ((keep >> r) & 1u) ? dpe * p.drop_scale : 0.f;
-                    de[i] = dead ? 0.f : pv * (dpe - dsum);
-                }
-                dsf[g >> 1][(g & 1) * 2 + 0] = E::pack2(de[0], de[1]);
-                dsf[g >> 1][(g & 1) * 2 + 1] = E::pack2(de[2], de[3]);
-            }
-            // dQ^T += K^T dS^T  (contraction over the 32 keys)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int rows = (kk * 32 + ks * 16) * C::TROW;
-#pragma unroll
-                for (int n = 0; n < NV; ++n) {
-                    const u32x2 lo = lds_read_tr16_8B(k_t, t_read_off[n] + rows);
-                    const u32x2 hi = lds_read_tr16_8B(k_t, t_read_off[n] + rows + 8 * C::TROW);
-                    dq[n] = E::mfma(u32x4{lo[0], lo[1], hi[0], hi[1]}, dsf[ks], dq[n]);
-                }
-            }
+            sub_block(st, kb, kk, std::true_type{});
         }
-    };
-    static_assert(C::NSTAGE == 2, "unrolled by the 2-slot ring");
-    for (int kb = 0; kb < nkb; kb += 2) {
-        ring_step(kb, std::integral_constant<int, 0>{});
-        if (kb + 1 < nkb) ring_step(kb + 1, std::integral_constant<int, 1>{});
     }
 
     if (!wave_has_rows || my_q >= seq_q) return;
-    uint16_t *dqg = reinterpret_cast<uint16_t *>(p.dq) + (q_row0 + my_q) * p.dq_rs + (int64_t)head * p.dq_hs;
+    uint16_t *dqg = reinterpret_cast<uint16_t *>(p.dq) + (si.q_row0 + my_q) * p.dq_rs + (int64_t)head * p.dq_hs;
 #pragma unroll
     for (int n = 0; n < NV; ++n)
 #pragma unroll
@@ -506,9 +633,9 @@ BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t
 
 // Kernels: a causal workgroup takes the heaviest remaining tile and the lightest of its (sample, head) -- tiles t
 // and n-1-t -- so that every workgroup carries the same work (in-order round-robin dispatch, see flash_fwd_dma.hip).
-template <class ET, int KD, int NV, bool DROP>
+template <class ET, int KD, bool FULLD, bool DROP>
 __global__ __launch_bounds__(256) void flash_bwd_dkdv_kernel(const FlashBwdParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[DkdvCfg<KD, NV>::SMEM];
+    __shared__ __attribute__((aligned(16))) char smem[DkdvCfg<KD>::SMEM];
     const uint32_t lds0 = lds_base_addr(smem);
     const int n = (p.max_sk + 127) / 128;
     const bool pair = p.causal && n > 1;
@@ -518,14 +645,14 @@ __global__ __launch_bounds__(256) void flash_bwd_dkdv_kernel(const FlashBwdParam
     const int npass = (pair && other != slot) ? 2 : 1;
     for (int pass = 0; pass < npass; ++pass) {
         if (pass) __syncthreads();
-        flash_bwd_dkdv_tile<ET, KD, NV, DROP>(p, smem, lds0, bh, pass ? other : slot);
+        flash_bwd_dkdv_tile<ET, KD, FULLD, DROP>(p, smem, lds0, bh, pass ? other : slot);
     }
 }
 
-template <class ET, int KD, int NV, bool DROP>
+template <class ET, int KD, bool FULLD, bool DROP>
 __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashBwdParams p) {
-    using C = BwdCfg<KD, NV>;
-    __shared__ __attribute__((aligned(16))) char smem[C::NSTAGE * (2 * C::RTILE + C::TTILE)];
+    using C = BwdCfg<KD>;
+    __shared__ __attribute__((aligned(16))) char smem[C::NSTAGE * 2 * C::TILE];
     const uint32_t lds0 = lds_base_addr(smem);
     const int n = (p.max_sq + 127) / 128;
     const bool pair = p.causal && n > 1;
@@ -535,39 +662,44 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashBwdParams 
     const int npass = (pair && heavy != slot) ? 2 : 1;
     for (int pass = 0; pass < npass; ++pass) {
         if (pass) __syncthreads();
-        flash_bwd_dq_tile<ET, KD, NV, DROP>(p, smem, lds0, bh, pass ? slot : heavy);
+        flash_bwd_dq_tile<ET, KD, FULLD, DROP>(p, smem, lds0, bh, pass ? slot : heavy);
     }
 }
 
-template <class ET, int KD, int NV, bool DROP>
+template <class ET, int KD, bool FULLD, bool DROP>
 static hipError_t launch_drop(const FlashBwdParams &p, hipStream_t stream) {
-    // dq first: it also produces the D vector the dkdv kernel consumes
+    // dq first: it also produces the row statistics the dkdv kernel consumes
     const int nq = (p.max_sq + 127) / 128, nk = (p.max_sk + 127) / 128;
     const int gq = xcd_grid(p.b * p.h, (p.causal && nq > 1) ? (nq + 1) / 2 : nq);
-    hipLaunchKernelGGL((flash_bwd_dq_kernel<ET, KD, NV, DROP>), dim3(gq), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((flash_bwd_dq_kernel<ET, KD, FULLD, DROP>), dim3(gq), dim3(256), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int gk = xcd_grid(p.b * p.h, (p.causal && nk > 1) ? (nk + 1) / 2 : nk);
-    hipLaunchKernelGGL((flash_bwd_dkdv_kernel<ET, KD, NV, DROP>), dim3(gk), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((flash_bwd_dkdv_kernel<ET, KD, FULLD, DROP>), dim3(gk), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 
-template <class ET, int KD, int NV>
+template <class ET, int KD>
 static hipError_t launch_one(const FlashBwdParams &p, hipStream_t stream) {
-    return p.drop_thr != 0u ? launch_drop<ET, KD, NV, true>(p, stream) : launch_drop<ET, KD, NV, false>(p, stream);
+    const bool drop = p.drop_thr != 0u;
+    if constexpr (KD == 4 || KD == 8) {
+        if (p.d == KD * 16)
+            return drop ? launch_drop<ET, KD, true, true>(p, stream) : launch_drop<ET, KD, true, false>(p, stream);
+    }
+    return drop ? launch_drop<ET, KD, false, true>(p, stream) : launch_drop<ET, KD, false, false>(p, stream);
 }
 
 template <class ET>
 static hipError_t launch_et(const FlashBwdParams &p, hipStream_t stream) {
     switch ((p.d + 15) / 16) {
-        case 1: return launch_one<ET, 1, 1>(p, stream);
-        case 2: return launch_one<ET, 2, 1>(p, stream);
-        case 3: return launch_one<ET, 3, 2>(p, stream);
-        case 4: return launch_one<ET, 4, 2>(p, stream);
-        case 5: return launch_one<ET, 5, 4>(p, stream);   // d_h = 80 (Mini)
-        case 6: return launch_one<ET, 6, 4>(p, stream);
-        case 7: return launch_one<ET, 7, 4>(p, stream);
-        default: return launch_one<ET, 8, 4>(p, stream);
+        case 1: return launch_one<ET, 1>(p, stream);
+        case 2: return launch_one<ET, 2>(p, stream);
+        case 3: return launch_one<ET, 3>(p, stream);
+        case 4: return launch_one<ET, 4>(p, stream);
+        case 5: return launch_one<ET, 5>(p, stream);   // d_h = 80 (Mini)
+        case 6: return launch_one<ET, 6>(p, stream);
+        case 7: return launch_one<ET, 7>(p, stream);
+        default: return launch_one<ET, 8>(p, stream);
     }
 }
 

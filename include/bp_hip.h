@@ -256,8 +256,9 @@ int bp_sense_dq_dk(const void *qk, const void *dpt, const float *lse, float *dsu
  *   q, dout, out, dq  (total_q, nheads, head_dim); k, v, dk, dv (total_k, nheads, head_dim): 16-bit, last
  *                stride 1, 16-byte aligned rows, head_dim % 8 == 0 and <= 128
  *   softmax_lse  (batch, nheads, lse_stride) fp32
- *   dsum_ws      (batch, nheads, lse_stride) fp32 workspace, contents undefined on entry: the kernels put
- *                D[b,h,i] = sum_d dout_i[d] * out_i[d] there (upstream's dsoftmax_sum, fmha_api.cpp:421)
+ *   dsum_ws      (batch, nheads, 2, lse_stride) fp32 workspace, contents undefined on entry: the kernels put the row
+ *                statistics there, -D[b,h,i] = -sum_d dout_i[d] * out_i[d] (upstream's dsoftmax_sum,
+ *                fmha_api.cpp:421) and -softmax_lse[b,h,i] / softmax_scale  (ABI 3: twice the ABI-2 size)
  *   cu_seqlens_*       as in bp_flash_fwd (NULL = fixed length)
  */
 int bp_flash_bwd(const void *dout, const void *q, const void *k, const void *v, const void *out,

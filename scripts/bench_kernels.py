@@ -1,7 +1,7 @@
 """Micro-benchmark of the individual HIP kernels on synthetic N(0,1) data (never zeros: zero-filled
 inputs clock higher and flatter -- cdna_hip_programming.md section 5.4 rule 25).
 
-    python scripts/bench_kernels.py [--which flash,bwd,mix,lse,alpha,mixbwd,lnbwd,xent] [--batch 64] [--seq 1024] [--iters 20]
+    python scripts/bench_kernels.py [--which flash,bwd,mix,lse,alpha,mixbwd,lnbwd,xent,gelu] [--batch 64] [--seq 1024] [--iters 20]
 Prints one JSON line per kernel with avg ms, algorithmic TFLOP/s and GB/s (SURVEY section 8d figures)."""
 import argparse
 import json
@@ -123,6 +123,22 @@ def main():
         g = torch.ones(rows, device=dev)
         ms = timeit(lambda: bp_hip.xentropy_bwd(g, x, lse, y, inplace=False), a.iters)
         res.append(dict(kernel='xentropy_bwd', rows=rows, ms=ms, tflops=0.0, gbps=rows * V * 4 / ms / 1e6))
+    if 'gelu' in which:
+        rows, cols = B * S, 4 * d
+        x = torch.randn(rows, cols, device=dev).to(dt)
+        g = (torch.randn(rows, cols, device=dev) / 8).to(dt)
+        y = torch.empty_like(x)
+        ms = timeit(lambda: bp_hip.bias_gelu_fwd(x, out=y), a.iters)
+        res.append(dict(kernel='bias_gelu_fwd', rows=rows, ms=ms, tflops=0.0, gbps=rows * cols * 4 / ms / 1e6))
+        ms = timeit(lambda: torch.nn.functional.gelu(x, approximate='tanh'), a.iters)
+        res.append(dict(kernel='torch gelu (same bytes)', rows=rows, ms=ms, tflops=0.0, gbps=rows * cols * 4 / ms / 1e6))
+        dp = torch.empty_like(x)
+        ms = timeit(lambda: bp_hip.bias_gelu_bwd(g, x, torch.float32), a.iters)
+        res.append(dict(kernel='bias_gelu_bwd(+dbias)', rows=rows, ms=ms, tflops=0.0, gbps=rows * cols * 6 / ms / 1e6))
+        ms = timeit(lambda: bp_hip.column_sum(g, torch.float32), a.iters)
+        res.append(dict(kernel='column_sum', rows=rows, ms=ms, tflops=0.0, gbps=rows * cols * 2 / ms / 1e6))
+        ms = timeit(lambda: g.sum(0), a.iters)
+        res.append(dict(kernel='torch sum(0) (same bytes)', rows=rows, ms=ms, tflops=0.0, gbps=rows * cols * 2 / ms / 1e6))
     for r in res:
         r.update(batch=r.get('batch', B), seq=S, dtype=a.dtype)
         print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}), flush=True)

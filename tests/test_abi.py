@@ -128,7 +128,7 @@ def test_argument_validation_returns_before_any_launch():
     assert h.bp_bias_gelu_bwd(p, null, p, null, null, 8, 64, 1, 1, null) == -3
     assert h.bp_column_sum(p, null, p, 8, 64, 1, 1, null) == -3
     assert h.bp_column_sum(p, p, p, 0, 64, 1, 1, null) == -3
-    assert h.bp_bias_grad_ws_floats(32768, 3072) == 3072 * 1366 and h.bp_bias_grad_ws_floats(3, 768) == 768 * 2
+    assert h.bp_bias_grad_ws_floats(32768, 3072) == 3072 * 171 and h.bp_bias_grad_ws_floats(3, 768) == 768 * 1
     assert h.bp_bias_grad_ws_floats(0, 768) == 0
 
 

@@ -268,21 +268,3 @@ def test_flash_forward_takes_a_torch_generator():
     state = g.get_state()
     run(g, 0.0)
     assert torch.equal(g.get_state(), state)
-
-
-def test_dropout_rescale_is_the_realised_keep_rate():
-    """E[dropout(x)] = x: the kernels rescale by 65536 / thr, the reciprocal of the keep rate the 16-bit threshold
-    realises (csrc/bp_api.hip dropout_args), also where the clamp of thr moves the rate (p within 2^-17 of 0 or 1)."""
-    bp = _bp()
-    rows, cols = 4096, 1024
-    x = torch.ones(rows, cols, device=DEV, dtype=torch.bfloat16)
-    w, bias = torch.ones(cols, device=DEV), torch.zeros(cols, device=DEV)
-    for p in (0.1, 0.999995):
-        _, xo, dmask = bp.add_layer_norm(x, None, w, bias, 1e-5, residual_dtype=torch.float32, dropout_p=p,
-                                         rng_state=_state(3, 4), return_dropout_mask=True)
-        thr = min(max(int(round((1 - p) * 65536)), 1), 65535)
-        kept = xo[dmask.bool()]
-        assert kept.numel() > 0 and (kept - 65536.0 / thr).abs().max().item() <= 65536.0 / thr * 2.0 ** -20
-        assert torch.count_nonzero(xo[~dmask.bool()]) == 0
-        if p == 0.1:
-            assert abs(xo.mean().item() - 1.0) < 2e-3
