@@ -454,7 +454,7 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
 
 }
 
-// Queue state of a persistent launch: one 64-byte record of device memory, zeroed by a memset node enqueued right in
+// Queue state of a persistent launch: one 64-byte record of device memory, zeroed by a one-wave kernel enqueued right in
 // front of the kernel (stream-ordered, so it is captured into a HIP graph with the launch and a launch that died
 // cannot leave a stale record behind).  The record belongs to ONE launch until that launch has completed:
 //   * callers that capture graphs or run launches concurrently on several streams pass their own record
@@ -479,11 +479,18 @@ static MixQueues *next_queue_record() {
     return base + (counter.fetch_add(1u, std::memory_order_relaxed) % kMixQueueRing);
 }
 
-// shared with the dC launch (sense_mix_bwd.hip)
+__global__ void arm_mix_queues_kernel(MixQueues *queues) {
+    if (threadIdx.x < 16) reinterpret_cast<unsigned int *>(queues)[threadIdx.x] = 0u;
+}
+
+// shared with the dC launch (sense_mix_bwd.hip).  A one-wave KERNEL, not hipMemsetAsync: captured into a HIP graph the
+// latter becomes a memset node, and replaying graphs of memset + persistent-kernel nodes faulted sporadically on
+// ROCm 7.2 (r03_f: graph replays alone, no eager launch in flight); a kernel node in front of a kernel node does not.
 hipError_t arm_mix_queues(MixQueues *&queues, hipStream_t stream) {
     if (queues == nullptr) queues = next_queue_record();
     if (queues == nullptr) return hipErrorInvalidDevice;
-    return hipMemsetAsync(queues, 0, sizeof(MixQueues), stream);
+    hipLaunchKernelGGL(arm_mix_queues_kernel, dim3(1), dim3(64), 0, stream, queues);
+    return hipGetLastError();
 }
 
 static int mix_persistent_grid() {

@@ -228,7 +228,22 @@ class BackpackModel(GPTPreTrainedModel):
             return bp_hip.sense_mix_autograd(qk, content.transpose(1, 2),
                                              self.contextualization_attn.scale())
         contextualization = self.contextualization_attn(contextl_hidden_states)   # (B,k,S,S)
-        return torch.sum(contextualization @ content, dim=1)                       # (B,S,d)
+        return _combine_senses(contextualization, content)                         # (B,S,d)
+
+
+def _combine_senses(contextualization, content):
+    """The reference's eager sense combination, torch.sum(contextualization @ content, dim=1)
+    (training/src/models/backpack.py:313).  One exception: 16-bit tensors on the GPU with gradients enabled take the
+    einsum restatement (identical to 1.2e-7 in fp32; here the sum over the senses is
+    accumulated in fp32 inside one GEMM instead of being a 16-bit sum of 16-bit products).  On ROCm 7.2 the BLAS
+    backward of the batched `contextualization @ content` in bf16 takes a memory fault at Backpack-Small dimensions
+    (k 16, S 1024, d 768 -- with or without a contiguous content, with or without a materialised gradient of the
+    sum; fp32 and the einsum form do not: scripts/debug/r03_blas_fault.py, profiles/r03_h_blas_fault.txt).  The HIP
+    path (use_flash_attn) never touches any of this."""
+    if contextualization.is_cuda and contextualization.dtype != torch.float32 and torch.is_grad_enabled() \
+            and (contextualization.requires_grad or content.requires_grad):
+        return torch.einsum('blts,blsd->btd', contextualization, content)
+    return torch.sum(contextualization @ content, dim=1)
 
 
 class BackpackLMHeadModel(BackpackPreTrainedModel, GenerationMixin):

@@ -51,6 +51,10 @@ namespace {
 #ifndef BP_BWD_NSTAGE
 #define BP_BWD_NSTAGE 2
 #endif
+// 1: the clean tiles of the no-dropout kernels weave their two sub-blocks (MFMA / softmax interleave inside the wave)
+#ifndef BP_BWD_PIPE
+#define BP_BWD_PIPE 1
+#endif
 
 template <int KD>
 struct BwdCfg {
@@ -370,12 +374,114 @@ BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32
             sub_block(st, qt, qb, std::true_type{});
         }
     };
-    // (the two sub-blocks woven inside the wave -- S/dP of B under A's softmax, dV/dK of A under B's -- needs 212
-    // VGPRs, i.e. two waves per SIMD, and measured 3-5 % slower than this plain body at three: scripts/probes/flash_bwd_woven)
+    // Clean tile, software-pipelined inside the wave.  Both pipes of a SIMD sit idle a third of the time when every wave
+    // runs "MFMAs, then softmax, then MFMAs" (r03_i PMC: MFMA 32 % busy, VALU 30 %, next to no overlap -- waves of
+    // different workgroups on a SIMD mostly take turns), so the two 32-query sub-blocks A and B of the tile are woven:
+    //   S/dP MFMAs of A | S/dP MFMAs of B, each followed by an eighth of A's softmax | dV/dK MFMAs of A, each followed
+    //   by an eighth of B's softmax | dV/dK MFMAs of B.
+    // hipcc gives pure arithmetic no source order; the empty asm statements pin it (compiler findings).
     auto clean_tile = [&](int qt) {
         const char *st = step_begin(qt);
-        sub_block(st, qt, 0, std::false_type{});
-        sub_block(st, qt, 1, std::false_type{});
+        if constexpr (DROP || !BP_BWD_PIPE) {
+            sub_block(st, qt, 0, std::false_type{});
+            sub_block(st, qt, 1, std::false_type{});
+        } else {
+            f32x16 sa, da, sb, db;
+            auto load_stats = [&](int qb, f32x16 &s_, f32x16 &dp) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const u32x4 l4 = lds_read_16B(st, G::L_OFF + (qb * 32 + 8 * g + 4 * hh) * 4);
+                    const u32x4 d4 = lds_read_16B(st, G::D_OFF + (qb * 32 + 8 * g + 4 * hh) * 4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t lw = l4[i], dw = d4[i];
+                        s_[4 * g + i] = as_f32(lw);
+                        dp[4 * g + i] = as_f32(dw);
+                    }
+                }
+            };
+            // elements 2e, 2e+1 of a sub-block: P and dS, packed into the B-operand words they belong to
+            auto soft2 = [&](f32x16 &s_, f32x16 &dp, int e, u32x4 (&pf)[2], u32x4 (&dsf)[2]) {
+                float x0 = s_[2 * e], x1 = s_[2 * e + 1], y0 = dp[2 * e], y1 = dp[2 * e + 1];
+                asm volatile("" : "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1));
+                x0 = fast_exp2(x0 * c2);
+                x1 = fast_exp2(x1 * c2);
+                y0 *= x0;
+                y1 *= x1;
+                uint32_t pw = E::pack2(x0, x1), dw = E::pack2(y0, y1);
+                asm volatile("" : "+v"(pw), "+v"(dw));
+                const int g = e >> 1;
+                pf[g >> 1][(g & 1) * 2 + (e & 1)] = pw;
+                dsf[g >> 1][(g & 1) * 2 + (e & 1)] = dw;
+            };
+            load_stats(0, sa, da);
+            load_stats(1, sb, db);
+#pragma unroll
+            for (int s = 0; s < KD; ++s) {
+                sa = E::mfma(lds_read_16B(st, G::Q_OFF + r_off[s]), kf[s], sa);
+                da = E::mfma(lds_read_16B(st, G::DO_OFF + r_off[s]), vf[s], da);
+            }
+            asm volatile("" : "+v"(sa), "+v"(da));
+            u32x4 pfa[2], dsfa[2], pfb[2], dsfb[2];
+            // S/dP of B (2 KD MFMAs) with A's softmax (8 slices) spread over them
+            constexpr int kPerMfmaA = (8 + 2 * KD - 1) / (2 * KD);
+            int ea = 0;
+#pragma unroll
+            for (int s = 0; s < KD; ++s) {
+                sb = E::mfma(lds_read_16B(st, G::Q_OFF + r_off[s] + 32 * C::ROW), kf[s], sb);
+                asm volatile("" : "+v"(sb));
+#pragma unroll
+                for (int t = 0; t < kPerMfmaA; ++t)
+                    if (ea < 8) soft2(sa, da, ea++, pfa, dsfa);
+                db = E::mfma(lds_read_16B(st, G::DO_OFF + r_off[s] + 32 * C::ROW), vf[s], db);
+                asm volatile("" : "+v"(db));
+#pragma unroll
+                for (int t = 0; t < kPerMfmaA; ++t)
+                    if (ea < 8) soft2(sa, da, ea++, pfa, dsfa);
+            }
+#pragma unroll
+            for (; ea < 8; ++ea) soft2(sa, da, ea, pfa, dsfa);
+            // dV/dK of A (4 NV MFMAs) with B's softmax spread over them
+            constexpr int kPerMfmaB = (8 + 4 * NV - 1) / (4 * NV);
+            int eb = 0;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int rows = ks * 16 * C::ROW;
+#pragma unroll
+                for (int n = 0; n < NV; ++n) {
+                    const u32x2 lo = lds_read_tr16_8B(st, G::DO_OFF + t_off[n][0] + rows);
+                    const u32x2 hi = lds_read_tr16_8B(st, G::DO_OFF + t_off[n][1] + rows);
+                    dv[n] = E::mfma(u32x4{lo[0], lo[1], hi[0], hi[1]}, pfa[ks], dv[n]);
+                    asm volatile("" : "+v"(dv[n]));
+#pragma unroll
+                    for (int t = 0; t < kPerMfmaB; ++t)
+                        if (eb < 8) soft2(sb, db, eb++, pfb, dsfb);
+                    const u32x2 lo2 = lds_read_tr16_8B(st, G::Q_OFF + t_off[n][0] + rows);
+                    const u32x2 hi2 = lds_read_tr16_8B(st, G::Q_OFF + t_off[n][1] + rows);
+                    dk[n] = E::mfma(u32x4{lo2[0], lo2[1], hi2[0], hi2[1]}, dsfa[ks], dk[n]);
+                    asm volatile("" : "+v"(dk[n]));
+#pragma unroll
+                    for (int t = 0; t < kPerMfmaB; ++t)
+                        if (eb < 8) soft2(sb, db, eb++, pfb, dsfb);
+                }
+            }
+#pragma unroll
+            for (; eb < 8; ++eb) soft2(sb, db, eb, pfb, dsfb);
+            // dV/dK of B
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int rows = (32 + ks * 16) * C::ROW;
+#pragma unroll
+                for (int n = 0; n < NV; ++n) {
+                    const u32x2 lo = lds_read_tr16_8B(st, G::DO_OFF + t_off[n][0] + rows);
+                    const u32x2 hi = lds_read_tr16_8B(st, G::DO_OFF + t_off[n][1] + rows);
+                    dv[n] = E::mfma(u32x4{lo[0], lo[1], hi[0], hi[1]}, pfb[ks], dv[n]);
+                    const u32x2 lo2 = lds_read_tr16_8B(st, G::Q_OFF + t_off[n][0] + rows);
+                    const u32x2 hi2 = lds_read_tr16_8B(st, G::Q_OFF + t_off[n][1] + rows);
+                    dk[n] = E::mfma(u32x4{lo2[0], lo2[1], hi2[0], hi2[1]}, dsfb[ks], dk[n]);
+                }
+            }
+        }
     };
 
     // Three sequential loops, one body each (an if/else join of the 2 x NV accumulator sets inside ONE loop makes the
@@ -659,9 +765,9 @@ BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t
 
 // Kernels: a causal workgroup takes the heaviest remaining tile and the lightest of its (sample, head) -- tiles t
 // and n-1-t -- so that every workgroup carries the same work (in-order round-robin dispatch, see flash_fwd_dma.hip).
-// (the dropout variants spill 500+ registers at three waves per SIMD: they keep two)
+// (the dropout variants spill 500+ registers at three waves per SIMD, the woven clean tile 67: they keep two)
 #ifndef BP_BWD_DKDV_MINWAVES
-#define BP_BWD_DKDV_MINWAVES(KD, DROP) ((KD) <= 4 && !(DROP) ? 3 : (KD) <= 4 ? 2 : 1)
+#define BP_BWD_DKDV_MINWAVES(KD, DROP) ((KD) <= 4 && !(DROP) && !BP_BWD_PIPE ? 3 : (KD) <= 4 ? 2 : 1)
 #endif
 
 template <class ET, int KD, bool FULLD, bool DROP>
