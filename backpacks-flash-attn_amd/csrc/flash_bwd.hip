@@ -44,6 +44,18 @@
 
 namespace bp {
 
+// Development builds only (-DBP_BWD_PROFILE, scripts/probes/flash_bwd_timeline): wave 0 of every workgroup stamps
+// s_memtime at the phases of each pass; never in the shipped library.
+#ifdef BP_BWD_PROFILE
+__device__ unsigned long long g_bwd_prof[2][8192][2][8];   // [kernel: 0 dq, 1 dkdv][workgroup][pass][stamp]
+#define BWD_STAMP(kern, pass, k)                                                                            \
+    do {                                                                                                     \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) g_bwd_prof[kern][blockIdx.x][pass][k] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define BWD_STAMP(kern, pass, k) do { } while (0)
+#endif
+
 namespace {
 
 // ring depth of the streamed tiles: tile t + NSTAGE - 1 is requested at the start of step t (three slots measured
@@ -98,6 +110,41 @@ template <int PER> BP_DEV void ring_wait(int ahead) {
     else wait_vmcnt<2 * PER>();
 }
 
+// Epilogue store of one accumulator block (rows d = 32 n + 8 g + 4 hh + i, column = lane l31) as 16-byte pieces: the
+// two half-waves own adjacent 8-byte pieces of every 16; v_permlane32_swap hands lanes 0..31 both pieces of the even
+// groups and lanes 32..63 both pieces of the odd groups.  `row` points at this lane's (key / query) row, element d = 0.
+// EXCHANGE = false: plain 8-byte pieces.  The kernels for head dims > 64 take that form: their dropout variants need
+// more than 256 registers (accumulators in AGPRs), and there the exchange form produced NaN dK / dV and memory faults
+// (r03_q: S = 200, d = 80, causal, p = 0.17; every other variant and the 8-byte form were right) -- a code-generation
+// problem around v_permlane32_swap that was not chased further.
+template <class E, bool EXCHANGE>
+BP_DEV void store_block16(uint16_t *row, const f32x16 &acc, float scale, int n, int hh, int d) {
+    if constexpr (!EXCHANGE) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d0 = n * 32 + 8 * g + 4 * hh;
+            if (d0 < d) {
+                u32x2 a = {E::pack2(acc[4 * g] * scale, acc[4 * g + 1] * scale),
+                           E::pack2(acc[4 * g + 2] * scale, acc[4 * g + 3] * scale)};
+                *reinterpret_cast<u32x2 *>(row + d0) = a;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; g += 2) {
+        uint32_t a0 = E::pack2(acc[4 * g] * scale, acc[4 * g + 1] * scale);
+        uint32_t a1 = E::pack2(acc[4 * g + 2] * scale, acc[4 * g + 3] * scale);
+        uint32_t b0 = E::pack2(acc[4 * g + 4] * scale, acc[4 * g + 5] * scale);
+        uint32_t b1 = E::pack2(acc[4 * g + 6] * scale, acc[4 * g + 7] * scale);
+        auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        const uint32_t w0 = r0[0], w1 = r1[0], w2 = r0[1], w3 = r1[1];   // by-value copies (bp_common.h, as_f32)
+        const int d0 = n * 32 + 8 * (g + hh);
+        if (d0 < d) *reinterpret_cast<u32x4 *>(row + d0) = u32x4{w0, w1, w2, w3};
+    }
+}
+
 struct SeqInfo {
     int seq_q, seq_k;
     int64_t q_row0, k_row0;
@@ -136,7 +183,9 @@ struct DkdvCfg {
 
 // one 128-key tile `kt` of (sample, head) `bh`
 template <class ET, int KD, bool FULLD, bool DROP>
-BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32_t lds0, const int bh, const int kt) {
+BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32_t lds0, const int bh, const int kt,
+                                  const int pass) {
+    BWD_STAMP(1, pass, 0);
     using C = BwdCfg<KD>;
     using G = DkdvCfg<KD>;
     using E = Elem<ET>;
@@ -190,7 +239,8 @@ BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32
     DropoutStream rng = {0u, 0u};
     if (DROP) rng = dropout_stream(p.rng_state, (uint32_t)bh);
 
-    // ---- K and V fragments of my 32 keys: B operands (lane = key, 8 consecutive d) -----------------
+    // ---- K and V fragments of my 32 keys: B operands (lane = key, 8 consecutive d).  Requested here, awaited behind
+    //      the first tile's DMA issue: the two latencies overlap (r03_n timeline: 3.9 k + 8 k ticks in sequence before)
     u32x4 kf[KD], vf[KD];
     {
         const int key = min(my_key, seq_k - 1);
@@ -205,8 +255,6 @@ BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32
             kf[s] = a;
             vf[s] = b;
         }
-#pragma unroll
-        for (int s = 0; s < KD; ++s) { settle(kf[s]); settle(vf[s]); }   // see bp_common.h: no vmcnt(0) in the loop
     }
 
     // ---- DMA: constant per-lane byte offsets, scalar tile pointers --------------------------------------
@@ -391,29 +439,31 @@ BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32
     clean_begin = min(clean_begin, nqt);
     clean_end = min(max(clean_end, clean_begin), nqt);
 
+    BWD_STAMP(1, pass, 2);   // descriptors done
     for (int t = 0; t < C::NSTAGE - 1; ++t)
         if (qt_begin + t < nqt) issue(qt_begin + t);
+#pragma unroll
+    for (int s = 0; s < KD; ++s) { settle(kf[s]); settle(vf[s]); }   // see bp_common.h: no vmcnt(0) in the loop
+    BWD_STAMP(1, pass, 1);   // K / V fragments arrived
     int qt = qt_begin;
-    for (; qt < clean_begin; ++qt) edge_tile(qt);
+    for (; qt < clean_begin; ++qt) { edge_tile(qt); if (qt == qt_begin) BWD_STAMP(1, pass, 3); }
+    BWD_STAMP(1, pass, 4);   // leading edge tiles done
     for (; qt < clean_end; ++qt) clean_tile(qt);
+    BWD_STAMP(1, pass, 5);   // clean tiles done
     for (; qt < nqt; ++qt) edge_tile(qt);
+    BWD_STAMP(1, pass, 6);   // all tiles done
 
-    if (!wave_has_keys || my_key >= seq_k) return;
-    uint16_t *dkg = reinterpret_cast<uint16_t *>(p.dk) + (si.k_row0 + my_key) * p.dk_rs + (int64_t)head * p.dk_hs;
-    uint16_t *dvg = reinterpret_cast<uint16_t *>(p.dv) + (si.k_row0 + my_key) * p.dv_rs + (int64_t)head * p.dv_hs;
+    if (!wave_has_keys) return;
+    const int key_row = min(my_key, seq_k - 1);
+    uint16_t *dkg = reinterpret_cast<uint16_t *>(p.dk) + (si.k_row0 + key_row) * p.dk_rs + (int64_t)head * p.dk_hs;
+    uint16_t *dvg = reinterpret_cast<uint16_t *>(p.dv) + (si.k_row0 + key_row) * p.dv_rs + (int64_t)head * p.dv_hs;
+    const int d_lim = my_key < seq_k ? p.d : 0;   // lanes past the sequence exchange, but store nothing
 #pragma unroll
-    for (int n = 0; n < NV; ++n)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int d0 = n * 32 + 8 * g + 4 * hh;
-            if (d0 < p.d) {
-                u32x2 a = {E::pack2(dk[n][4 * g] * p.scale, dk[n][4 * g + 1] * p.scale),
-                           E::pack2(dk[n][4 * g + 2] * p.scale, dk[n][4 * g + 3] * p.scale)};
-                u32x2 b = {E::pack2(dv[n][4 * g], dv[n][4 * g + 1]), E::pack2(dv[n][4 * g + 2], dv[n][4 * g + 3])};
-                *reinterpret_cast<u32x2 *>(dkg + d0) = a;
-                *reinterpret_cast<u32x2 *>(dvg + d0) = b;
-            }
-        }
+    for (int n = 0; n < NV; ++n) {
+        store_block16<E, (KD <= 4)>(dkg, dk[n], p.scale, n, hh, d_lim);
+        store_block16<E, (KD <= 4)>(dvg, dv[n], 1.f, n, hh, d_lim);
+    }
+    BWD_STAMP(1, pass, 7);   // stores issued
 }
 
 // =====================================================================================================
@@ -421,7 +471,9 @@ BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32
 // =====================================================================================================
 // one 128-query tile `qt` of (sample, head) `bh`
 template <class ET, int KD, bool FULLD, bool DROP>
-BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t lds0, const int bh, const int qt) {
+BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t lds0, const int bh, const int qt,
+                                const int pass) {
+    BWD_STAMP(0, pass, 0);
     using C = BwdCfg<KD>;
     using E = Elem<ET>;
     constexpr int NV = C::NV;
@@ -463,12 +515,12 @@ BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t
     DropoutStream rng = {0u, 0u};
     if (DROP) rng = dropout_stream(p.rng_state, (uint32_t)bh);
 
-    u32x4 qf[KD], dof[KD];
-    float lneg = 0.f, dneg = 0.f;   // -L / scale, -D of my row
+    // my row's Q, dO, O fragments and L: requested here, consumed behind the first tile's DMA issue
+    u32x4 qf[KD], dof[KD], of[KD];
+    float lse_row;
     {
         const int q = min(my_q, seq_q - 1);
         const uint16_t *og = reinterpret_cast<const uint16_t *>(p.out) + (si.q_row0 + q) * p.o_rs + (int64_t)head * p.o_hs;
-        float part = 0.f;   // my 8*KD columns of dO . O
 #pragma unroll
         for (int s = 0; s < KD; ++s) {
             const int col = 16 * s + 8 * hh;
@@ -480,32 +532,15 @@ BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t
             }
             qf[s] = a;
             dof[s] = b;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t bw = b[i], ow = o[i];   // by-value copies (bp_common.h, as_f32)
-                part = fmaf(E::lo_f32(bw), E::lo_f32(ow), part);
-                part = fmaf(E::hi_f32(bw), E::hi_f32(ow), part);
-            }
+            of[s] = o;
         }
-        const float lse = p.lse[((int64_t)batch * p.h + head) * p.lse_stride + q];
-        // (a row without keys has L = -inf and meets no key tile: any finite stand-in will do)
-        lneg = lse == -INFINITY ? 0.f : -lse / p.scale;
-        dneg = -xhalf_sum(part);   // the two half-waves hold the two 8-column halves of every 16
-        if (hh == 0 && wave_has_rows && my_q < seq_q) {
-            float *st = stats_row(p, batch, head);
-            st[q] = dneg;
-            st[p.lse_stride + q] = lneg;
-        }
-#pragma unroll
-        for (int s = 0; s < KD; ++s) { settle(qf[s]); settle(dof[s]); }
-        settle(lneg); settle(dneg);
+        lse_row = p.lse[((int64_t)batch * p.h + head) * p.lse_stride + q];
     }
-    // -D as the MFMA C operand of the first K-step of every dP chain (never written: the chains start from it); -L is
-    // a per-lane scalar here and rides the exponent's fma for free
+    // row constants, filled in behind the first DMA issue (below): -L / scale, -D of my row; -D as the MFMA C operand
+    // of the first K-step of every dP chain (never written: the chains start from it); -L is a per-lane scalar here
+    // and rides the exponent's fma for free
+    float lneg = 0.f, dneg = 0.f, lneg2 = 0.f;
     f32x16 c_d;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) c_d[r] = DROP ? 0.f : dneg;
-    const float lneg2 = lneg * c2;
 
     // ---- DMA -----------------------------------------------------------------------------------------------
     const int kb_partial = (seq_k % C::BT) != 0 ? seq_k / C::BT : -1;
@@ -622,14 +657,46 @@ BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t
     const int my_nkb = !wave_has_rows ? 0 : p.causal ? min(nkb, (q0 + 31) / C::BT + 1) : nkb;
     const int my_clean_end = !wave_has_rows ? 0 : p.causal ? min(seq_k / C::BT, (q0 + 1) / C::BT) : seq_k / C::BT;
 
+    BWD_STAMP(0, pass, 2);
     for (int t = 0; t < C::NSTAGE - 1; ++t)
         if (t < nkb) issue(t);
+
+    {
+        float part = 0.f;   // my 8*KD columns of dO . O
+#pragma unroll
+        for (int s = 0; s < KD; ++s) {
+            const u32x4 b = dof[s], o = of[s];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t bw = b[i], ow = o[i];   // by-value copies (bp_common.h, as_f32)
+                part = fmaf(E::lo_f32(bw), E::lo_f32(ow), part);
+                part = fmaf(E::hi_f32(bw), E::hi_f32(ow), part);
+            }
+        }
+        // (a row without keys has L = -inf and meets no key tile: any finite stand-in will do)
+        lneg = lse_row == -INFINITY ? 0.f : -lse_row / p.scale;
+        dneg = -xhalf_sum(part);   // the two half-waves hold the two 8-column halves of every 16
+        if (hh == 0 && wave_has_rows && my_q < seq_q) {
+            float *st = stats_row(p, batch, head);
+            st[min(my_q, seq_q - 1)] = dneg;
+            st[p.lse_stride + min(my_q, seq_q - 1)] = lneg;
+        }
+#pragma unroll
+        for (int s = 0; s < KD; ++s) { settle(qf[s]); settle(dof[s]); }
+        settle(lneg); settle(dneg);
+    }
+    BWD_STAMP(0, pass, 1);   // Q / dO / O / L arrived, D formed
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c_d[r] = DROP ? 0.f : dneg;
+    lneg2 = lneg * c2;
     int kb = 0;
     for (; kb < min(my_clean_end, nkb); ++kb) {
         const char *st = step_begin(kb);
+        if (kb == 0) BWD_STAMP(0, pass, 3);   // first tile landed
         sub_block(st, kb, 0, std::false_type{});
         sub_block(st, kb, 1, std::false_type{});
     }
+    BWD_STAMP(0, pass, 5);   // clean tiles done
     for (; kb < nkb; ++kb) {
         const char *st = step_begin(kb);
         if (kb >= my_nkb) continue;
@@ -641,20 +708,14 @@ BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t
             sub_block(st, kb, kk, std::true_type{});
         }
     }
+    BWD_STAMP(0, pass, 6);   // all tiles done
 
-    if (!wave_has_rows || my_q >= seq_q) return;
-    uint16_t *dqg = reinterpret_cast<uint16_t *>(p.dq) + (si.q_row0 + my_q) * p.dq_rs + (int64_t)head * p.dq_hs;
+    if (!wave_has_rows) return;
+    uint16_t *dqg = reinterpret_cast<uint16_t *>(p.dq) + (si.q_row0 + min(my_q, seq_q - 1)) * p.dq_rs + (int64_t)head * p.dq_hs;
+    const int d_lim = my_q < seq_q ? p.d : 0;
 #pragma unroll
-    for (int n = 0; n < NV; ++n)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int d0 = n * 32 + 8 * g + 4 * hh;
-            if (d0 < p.d) {
-                u32x2 a = {E::pack2(dq[n][4 * g] * p.scale, dq[n][4 * g + 1] * p.scale),
-                           E::pack2(dq[n][4 * g + 2] * p.scale, dq[n][4 * g + 3] * p.scale)};
-                *reinterpret_cast<u32x2 *>(dqg + d0) = a;
-            }
-        }
+    for (int n = 0; n < NV; ++n) store_block16<E, (KD <= 4)>(dqg, dq[n], p.scale, n, hh, d_lim);
+    BWD_STAMP(0, pass, 7);
 }
 
 // Kernels: a causal workgroup takes the heaviest remaining tile and the lightest of its (sample, head) -- tiles t
@@ -676,7 +737,7 @@ __global__ __launch_bounds__(256, BP_BWD_DKDV_MINWAVES(KD, DROP)) void flash_bwd
     const int npass = (pair && other != slot) ? 2 : 1;
     for (int pass = 0; pass < npass; ++pass) {
         if (pass) __syncthreads();
-        flash_bwd_dkdv_tile<ET, KD, FULLD, DROP>(p, smem, lds0, bh, pass ? other : slot);
+        flash_bwd_dkdv_tile<ET, KD, FULLD, DROP>(p, smem, lds0, bh, pass ? other : slot, pass);
     }
 }
 
@@ -698,7 +759,7 @@ __global__ __launch_bounds__(256, BP_BWD_DQ_MINWAVES(KD)) void flash_bwd_dq_kern
     const int npass = (pair && heavy != slot) ? 2 : 1;
     for (int pass = 0; pass < npass; ++pass) {
         if (pass) __syncthreads();
-        flash_bwd_dq_tile<ET, KD, FULLD, DROP>(p, smem, lds0, bh, pass ? slot : heavy);
+        flash_bwd_dq_tile<ET, KD, FULLD, DROP>(p, smem, lds0, bh, pass ? slot : heavy, pass);
     }
 }
 
@@ -744,5 +805,16 @@ hipError_t launch_flash_bwd(const FlashBwdParams &p, int dtype, hipStream_t stre
     if (p.d > 128) return hipErrorNotSupported;
     return dtype == 1 ? launch_et<BF16>(p, stream) : launch_et<F16>(p, stream);
 }
+
+#ifdef BP_BWD_PROFILE
+extern "C" int bp_dev_bwd_prof(unsigned long long *host, int clear) {
+    if (clear) {
+        void *ptr = nullptr;
+        if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_bwd_prof)) != hipSuccess) return -1;
+        return hipMemset(ptr, 0, sizeof(g_bwd_prof)) == hipSuccess ? 0 : -1;
+    }
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bwd_prof), sizeof(g_bwd_prof)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // namespace bp

@@ -128,8 +128,9 @@ def pick_batch(model, make_ids, candidates, seq, device, steps=3):
     """Untimed-region batch sweep ("B swept ... to the max that fits"): tokens/s of `steps`
     forwards at each candidate batch after 2 warm-up forwards.  A candidate whose footprint, extrapolated from the
     previous one's peak, would pass 90 % of HBM is not attempted; one that still runs out is recorded as such.
-    The smallest batch within 0.5 % of the best rate wins (the curve is flat once the GEMMs are at their rate).
-    Returns (batch, the sweep table)."""
+    The LARGEST batch within 0.5 % of the best rate wins: the curve is flat once the GEMMs are at their rate, and
+    north_star asks for the batch that fills the 288 GB (Small, S = 1024: 2560 samples = 250 GB = 87 % of HBM; the next
+    candidate would pass the 90 % guard).  Returns (batch, the sweep table)."""
     table = []
     total_mem = torch.cuda.get_device_properties(device).total_memory
     per_sample = None
@@ -162,7 +163,7 @@ def pick_batch(model, make_ids, candidates, seq, device, steps=3):
     best = max(r['tokens_per_s'] for r in table)
     if not best:
         raise SystemExit('no candidate batch fits in HBM')
-    pick = min(r['batch'] for r in table if r['tokens_per_s'] >= 0.995 * best)
+    pick = max(r['batch'] for r in table if r['tokens_per_s'] >= 0.995 * best)
     return pick, table
 
 
@@ -259,7 +260,7 @@ def main():
     sweep = None
     if args.batch == 'auto':
         cands = ([int(c) for c in args.batch_candidates.split(',')] if args.batch_candidates
-                 else [default_batch * m for m in (1, 2, 4, 8, 16, 24)])
+                 else [default_batch * m for m in (1, 2, 4, 8, 16, 24, 32, 40)])
         batch, sweep = pick_batch(model, make_ids, cands, seq, device)
         if dist is not None:    # every rank runs the batch rank 0 picked
             t = torch.tensor([batch], device=device)
@@ -294,9 +295,11 @@ def main():
             graph.replay()
             return graph_out
 
+    out = None
     for _ in range(args.warmup):
+        out = None          # never two logits tensors alive: at the HBM-filling batch one of them is most of the memory
         out = step()
-    del out
+    out = None
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -304,6 +307,7 @@ def main():
     clock.enabled = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        out = None
         out = step()
     torch.cuda.synchronize()
     if dist is not None:
@@ -354,7 +358,7 @@ def main():
                                    f'{cfg.n_head} heads, {cfg.n_layer} layers, k={cfg.num_content_vectors} '
                                    f'senses, vocab {cfg.vocab_size}, seq {seq}',
                        'batch_per_gpu': batch, 'global_batch': batch * world, 'seq_len': seq,
-                       'batch_choice': 'auto: smallest batch within 0.5 % of the best rate in batch_sweep' if sweep else 'given',
+                       'batch_choice': 'auto: largest batch within 0.5 % of the best rate in batch_sweep (fills HBM)' if sweep else 'given',
                        'parallelism': f'{world} independent batch replicas (no data-path collective)'},
         }
         if kernel_rows:
@@ -387,6 +391,15 @@ def main():
                                     'frac': dom['mfma_frac'], 'traffic': traffic,
                                     'traffic_source': traffic_source, 'avg_launch_ms': dom['avg_ms'], 'hbm_gbps': dom['gbps'],
                                     'hbm_frac': dom['hbm_frac']}
+            # the HBM-bound fused add + LayerNorm is excluded from `roofline` BY RULE (the path north_star names is the
+            # attention tile / sense contraction) even when its total time is the largest of this repository's kernels:
+            # its own roofline rides along here
+            ln = next((r for r in kernel_rows if r['kernel'] == 'add_layer_norm_kernel'), None)
+            if ln is not None and dom['kernel'] != 'add_layer_norm_kernel':
+                line['roofline']['excluded_by_rule'] = {
+                    'kernel': ln['kernel'], 'why': 'memory-bound glue around the attention path, not the path itself',
+                    'bound': 'hbm', 'achieved': ln['gbps'], 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': ln['hbm_frac'],
+                    'launches_per_step': ln['launches_per_step'], 'total_ms': ln['total_ms'], 'avg_launch_ms': ln['avg_ms']}
             line['kernels'] = kernel_rows
         if sweep:
             line['batch_sweep'] = sweep
