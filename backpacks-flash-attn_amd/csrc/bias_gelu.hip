@@ -214,12 +214,17 @@ int bias_gelu_bwd_slices(int64_t rows, int cols) {
     return (int)(nsl < 1 ? 1 : nsl);
 }
 
+// rows per trip of the dGELU kernel (two 16-byte loads each)
+#ifndef BP_GELU_BWD_ROWS
+#define BP_GELU_BWD_ROWS 4
+#endif
+
 template <class ET>
 static hipError_t bwd_et(const BiasGeluParams &p, bool gelu, hipStream_t stream) {
     const int chunks = (p.cols + 511) / 512;
     const int nsl = bias_gelu_bwd_slices(p.rows, p.cols);
     dim3 g(chunks, nsl), t(256);
-    if (gelu) hipLaunchKernelGGL((bias_gelu_bwd_kernel<ET, true, 4>), g, t, 0, stream, p);
+    if (gelu) hipLaunchKernelGGL((bias_gelu_bwd_kernel<ET, true, BP_GELU_BWD_ROWS>), g, t, 0, stream, p);
     else hipLaunchKernelGGL((bias_gelu_bwd_kernel<ET, false, 8>), g, t, 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || p.dbias == nullptr) return e;

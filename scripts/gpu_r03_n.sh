@@ -11,9 +11,5 @@ B=$(grep -h "^{" $O/r03_n_bench_small1024_auto.log | python -c "import sys,json;
 prof() { tag=$1; shift; (cd /tmp && export TMPDIR=/tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d $O/prof_$tag -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 5 --warmup 2 "$@" > $O/prof_$tag.log 2>&1)
   db=$(ls $O/prof_$tag/*/*_results.db 2>/dev/null | head -1); [ -n "$db" ] && python scripts/rocprof_summary.py $db $O/r03_n_kernel_stats_$tag.txt > /dev/null; rm -rf $O/prof_$tag; }
 prof small1024_b$B --batch $B
-for b in 512 2048 $B; do bash scripts/gpu_pmc.sh r03_n_small_b$b --which flash,lse,mix --batch $b --iters 3 > /dev/null 2>&1; cp $O/pmc_r03_n_small_b$b/summary.txt $O/r03_n_pmc_small_b$b.txt; rm -rf $O/pmc_r03_n_small_b$b; done
+for b in 512 2048 2304; do bash scripts/gpu_pmc.sh r03_n_small_b$b --which flash,lse,mix --batch $b --iters 3 > /dev/null 2>&1; cp $O/pmc_r03_n_small_b$b/summary.txt $O/r03_n_pmc_small_b$b.txt; rm -rf $O/pmc_r03_n_small_b$b; done
 echo "picked batch $B"; grep -h "^{" $O/r03_n_bench_*.log | cut -c1-600
-# timeline of the backward passes (development build)
-BP_HIP_LIB=$GRAFT_REPO_ROOT/backpacks-flash-attn_amd/bp_hip/libbackpack_hip_bwdprof.so timeout 300 python scripts/probes/flash_bwd_timeline/timeline.py --batch 64 > $O/r03_n_bwd_timeline_b64.txt 2>&1
-BP_HIP_LIB=$GRAFT_REPO_ROOT/backpacks-flash-attn_amd/bp_hip/libbackpack_hip_bwdprof.so timeout 300 python scripts/probes/flash_bwd_timeline/timeline.py --batch 64 --noncausal > $O/r03_n_bwd_timeline_b64_noncausal.txt 2>&1
-cat $O/r03_n_bwd_timeline_b64.txt
