@@ -104,9 +104,25 @@ class ContextSelfAttn(nn.Module):
         pad = (-dk) % 8 if self.use_hip else 0
         if pad == 0:
             return self.Wqkv(encoded).reshape(b, s, 2, k, dk)
-        w = F.pad(self.Wqkv.weight.view(2, k, dk, d), (0, 0, 0, pad)).view(2 * k * (dk + pad), d)
-        bias = F.pad(self.Wqkv.bias.view(2, k, dk), (0, pad)).view(-1)
+        w, bias = self._padded_projection(k, dk, pad, d)
         return fused_dense_func(encoded, w, bias).view(b, s, 2, k, dk + pad)
+
+    def _padded_projection(self, k, dk, pad, d):
+        """`Wqkv` with `pad` zero rows appended to every sense's q and k block.  Under autograd the pad is part of the
+        graph (gradients flow back to the unpadded parameter); without it (inference) the padded copy is kept until the
+        parameter changes -- `_version` moves on every in-place update, `data_ptr` on a reload / `.to()`."""
+        weight, bias = self.Wqkv.weight, self.Wqkv.bias
+        if torch.is_grad_enabled() and (weight.requires_grad or bias.requires_grad):
+            return (F.pad(weight.view(2, k, dk, d), (0, 0, 0, pad)).view(2 * k * (dk + pad), d),
+                    F.pad(bias.view(2, k, dk), (0, pad)).view(-1))
+        key = (weight.data_ptr(), weight._version, bias.data_ptr(), bias._version, weight.dtype, weight.device)
+        cached = getattr(self, '_padded_cache', None)
+        if cached is None or cached[0] != key:
+            with torch.no_grad():
+                cached = (key, F.pad(weight.view(2, k, dk, d), (0, 0, 0, pad)).view(2 * k * (dk + pad), d),
+                          F.pad(bias.view(2, k, dk), (0, pad)).view(-1))
+            self._padded_cache = cached
+        return cached[1], cached[2]
 
     def scale(self):
         """softmax scale of the TRUE sense width d/k (reference :117), whatever `project` padded to."""

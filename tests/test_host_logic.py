@@ -340,3 +340,28 @@ def test_product_never_touches_the_oracle():
     bench = open(os.path.join(ROOT, 'bench.py')).read()
     uses = [m.start() for m in pat.finditer(bench)]
     assert len(uses) == 1 and 'def cpu_baseline' in bench[:uses[0]] and bench.rfind('def ', 0, uses[0]) == bench.find('def cpu_baseline')
+
+
+def test_padded_sense_projection_is_cached_in_inference_and_tracks_the_parameter():
+    """d_k = 10 (Mini k = 64): `ContextSelfAttn.project` widens the senses to 16 with zero weight rows.  Without autograd
+    the padded copy is reused until the parameter changes; under autograd it stays part of the graph."""
+    from src.models.backpack import ContextSelfAttn
+    torch.manual_seed(0)
+    attn = ContextSelfAttn(8, 80, use_hip=True)            # d_k = 10 -> 16
+    x = torch.randn(2, 5, 80)
+    with torch.no_grad():
+        a = attn.project(x)
+        w1 = attn._padded_cache[1]
+        b = attn.project(x)
+        assert attn._padded_cache[1] is w1                  # no second pad
+        assert a.shape == (2, 5, 2, 8, 16) and torch.count_nonzero(a[..., 10:]) == 0
+        plain = torch.nn.functional.linear(x, attn.Wqkv.weight, attn.Wqkv.bias).reshape(2, 5, 2, 8, 10)
+        assert torch.equal(a[..., :10], plain) and torch.equal(a, b)
+        attn.Wqkv.weight.mul_(2.0)                          # in-place update: the version moves, the cache follows
+        c = attn.project(x)
+        assert attn._padded_cache[1] is not w1
+        assert torch.allclose(c[..., :10], torch.nn.functional.linear(x, attn.Wqkv.weight, attn.Wqkv.bias).reshape(2, 5, 2, 8, 10))
+    out = attn.project(x)                                   # autograd: gradients reach the unpadded parameter
+    out.square().sum().backward()
+    assert attn.Wqkv.weight.grad is not None and attn.Wqkv.weight.grad.shape == attn.Wqkv.weight.shape
+    assert '_padded_cache' not in attn.state_dict()
