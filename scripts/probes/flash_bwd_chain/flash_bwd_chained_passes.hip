@@ -63,8 +63,10 @@ namespace {
 #ifndef BP_BWD_NSTAGE
 #define BP_BWD_NSTAGE 2
 #endif
-// (the two passes of a paired causal workgroup chained into one tile stream, so that the ring never drains between
-// them: correct and 7 % slower, scripts/probes/flash_bwd_chain)
+// 1: the two passes of a paired causal workgroup run as one tile stream (flash_bwd_*_chain below)
+#ifndef BP_BWD_CHAIN
+#define BP_BWD_CHAIN 1
+#endif
 
 template <int KD>
 struct BwdCfg {
@@ -721,6 +723,537 @@ BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t
 }
 
 
+// =====================================================================================================
+// The two passes of a causal workgroup as ONE tile stream (BP_BWD_CHAIN): the ring never drains between the passes --
+// the second pass's first tile is requested during the first pass's last step, its operand fragments are requested
+// before the first pass's epilogue stores -- so the second pass starts without the two latencies in sequence that the
+// timeline shows at every pass start (scripts/probes/flash_bwd_timeline).
+// =====================================================================================================
+template <class ET, int KD, bool FULLD, bool DROP>
+BP_DEV void flash_bwd_dkdv_chain(const FlashBwdParams p, char *smem, const uint32_t lds0, const int bh, const int kt_a,
+                                   const int kt_b) {
+    using C = BwdCfg<KD>;
+    using G = DkdvCfg<KD>;
+    using E = Elem<ET>;
+    constexpr int NV = C::NV;
+    static_assert(C::NSTAGE == 2, "the chained stream is written for the 2-slot ring");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int hh = lane >> 5;
+
+    const int batch = bh / p.h;
+    const int head = bh - batch * p.h;
+    const SeqInfo si = seq_info(p, batch);
+    const int seq_q = si.seq_q, seq_k = si.seq_k;
+
+    const uint16_t *qg = reinterpret_cast<const uint16_t *>(p.q) + si.q_row0 * p.q_rs + (int64_t)head * p.q_hs;
+    const uint16_t *dog = reinterpret_cast<const uint16_t *>(p.dout) + si.q_row0 * p.do_rs + (int64_t)head * p.do_hs;
+    const uint16_t *kg = reinterpret_cast<const uint16_t *>(p.k) + si.k_row0 * p.k_rs + (int64_t)head * p.k_hs;
+    const uint16_t *vg = reinterpret_cast<const uint16_t *>(p.v) + si.k_row0 * p.v_rs + (int64_t)head * p.v_hs;
+    const float *stats_g = stats_row(p, batch, head);
+    const float c2 = p.scale * kLog2e;
+    const int nqt = (seq_q + C::BT - 1) / C::BT;
+
+    // a pass = one 128-key tile kt; it exists when it holds keys, and streams the query tiles [first, nqt)
+    auto pass_exists = [&](int kt_) { return kt_ >= 0 && kt_ * 128 < seq_k; };
+    auto pass_first = [&](int kt_) { return p.causal ? (kt_ * 128) / C::BT : 0; };
+    auto pass_tiles = [&](int kt_) { return pass_exists(kt_) ? max(nqt - pass_first(kt_), 0) : 0; };
+    const int kts[2] = {kt_a, kt_b};
+
+    if (!FULLD) {   // pad slots of the images must read as 0 (they meet zero K / V columns in the MFMAs)
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (int off = tid * 16; off < G::SMEM; off += C::NT * 16) lds_write_16B(smem, off, z);
+        __syncthreads();
+    }
+    DropoutStream rng = {0u, 0u};
+    if (DROP) rng = dropout_stream(p.rng_state, (uint32_t)bh);
+
+    // ---- DMA: constant per-lane byte offsets, scalar tile pointers, one issue cursor over both passes -------
+    const int qt_partial = (seq_q % C::BT) != 0 ? seq_q / C::BT : -1;
+    const int last_row = seq_q - 1 - (seq_q / C::BT) * C::BT;
+    uint32_t q_voff[C::DMA], do_voff[C::DMA], q_voff_p[C::DMA], do_voff_p[C::DMA];
+    bool piece_live[C::DMA];
+#pragma unroll
+    for (int j = 0; j < C::DMA; ++j) {
+        int row, col;
+        piece<C>(wave, lane, j, row, col);
+        piece_live[j] = FULLD || col < p.d;
+        q_voff[j] = (uint32_t)(row * p.q_rs + col) * 2u;
+        do_voff[j] = (uint32_t)(row * p.do_rs + col) * 2u;
+        q_voff_p[j] = (uint32_t)(min(row, last_row) * p.q_rs + col) * 2u;
+        do_voff_p[j] = (uint32_t)(min(row, last_row) * p.do_rs + col) * 2u;
+    }
+    const int64_t q_tile_stride = (int64_t)C::BT * p.q_rs, do_tile_stride = (int64_t)C::BT * p.do_rs;
+    int iss_pass = 0, iss_left = pass_tiles(kts[0]), iss_qt = pass_first(kts[0]), g_iss = 0;
+    if (iss_left == 0) { iss_pass = 1; iss_left = pass_tiles(kts[1]); iss_qt = pass_first(kts[1]); }
+    const uint16_t *qt_ptr = qg + (int64_t)iss_qt * q_tile_stride;
+    const uint16_t *dot_ptr = dog + (int64_t)iss_qt * do_tile_stride;
+    auto issue_next = [&]() {
+        if (iss_left == 0) return;
+        const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + (g_iss & 1) * G::STAGE);
+        const bool partial = iss_qt == qt_partial;
+#pragma unroll
+        for (int j = 0; j < C::DMA; ++j)
+            if (piece_live[j]) {
+                dma16_s(qt_ptr, partial ? q_voff_p[j] : q_voff[j],
+                        __builtin_amdgcn_readfirstlane(st + G::Q_OFF + (wave * C::DMA + j) * 1024));
+                dma16_s(dot_ptr, partial ? do_voff_p[j] : do_voff[j],
+                        __builtin_amdgcn_readfirstlane(st + G::DO_OFF + (wave * C::DMA + j) * 1024));
+            }
+        if (wave < 2) {
+            const float *src = stats_g + wave * p.lse_stride + min(iss_qt * C::BT + lane, (int)p.lse_stride - 1);
+            dma4(src, st + G::D_OFF + wave * 256);
+        }
+        ++g_iss; ++iss_qt; --iss_left;
+        qt_ptr += q_tile_stride;
+        dot_ptr += do_tile_stride;
+        if (iss_left == 0 && iss_pass == 0) {
+            iss_pass = 1; iss_left = pass_tiles(kts[1]); iss_qt = pass_first(kts[1]);
+            qt_ptr = qg + (int64_t)iss_qt * q_tile_stride;
+            dot_ptr = dog + (int64_t)iss_qt * do_tile_stride;
+        }
+    };
+
+    int r_off[KD];   // A operand rows (lane = query l31)
+#pragma unroll
+    for (int s = 0; s < KD; ++s) r_off[s] = row_read_off<C>(l31, hh, s);
+    int t_off[NV][2];   // transposing reads: head-dim block n, rows +0 / +8
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+        t_off[n][0] = tr_read_off<C>(lane, n, 0);
+        t_off[n][1] = tr_read_off<C>(lane, n, 1);
+    }
+
+    // ---- per-pass state ---------------------------------------------------------------------------------
+    int key0 = 0, my_key = 0;
+    bool wave_has_keys = false;
+    u32x4 kf[KD], vf[KD];
+    f32x16 dk[NV], dv[NV];
+    auto request_fragments = [&](int kt_) {   // K and V rows of my 32 keys of tile kt_: B operands
+        const int key = min(kt_ * 128 + wave * 32 + l31, seq_k - 1);
+#pragma unroll
+        for (int s = 0; s < KD; ++s) {
+            const int col = 16 * s + 8 * hh;
+            u32x4 a = {0u, 0u, 0u, 0u}, b = {0u, 0u, 0u, 0u};
+            if (FULLD || col < p.d) {
+                a = ld_global_16B(kg + (int64_t)key * p.k_rs + col);
+                b = ld_global_16B(vg + (int64_t)key * p.v_rs + col);
+            }
+            kf[s] = a;
+            vf[s] = b;
+        }
+    };
+
+    // One 32-query sub-block `qb` of the tile in `st`.  EDGE: mask what is not a (query, key) pair of the problem.
+    auto sub_block = [&](const char *st, int qt, int qb, auto EDGE) {
+        constexpr bool kEdge = decltype(EDGE)::value;
+        const int qbase = qt * C::BT + qb * 32;          // first query of this sub-block
+        // ---- S = Q K^T - L/scale and dP = dO V^T - D : rows = queries (registers), column = my key; the row
+        //      constants are the accumulators' initial values
+        f32x16 s_, dp;
+        float dneg[DROP ? 16 : 1];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const u32x4 l4 = lds_read_16B(st, G::L_OFF + (qb * 32 + 8 * g + 4 * hh) * 4);
+            const u32x4 d4 = lds_read_16B(st, G::D_OFF + (qb * 32 + 8 * g + 4 * hh) * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t lw = l4[i], dw = d4[i];   // by-value copies (bp_common.h, as_f32)
+                s_[4 * g + i] = as_f32(lw);
+                if (DROP) { dp[4 * g + i] = 0.f; dneg[4 * g + i] = as_f32(dw); }
+                else dp[4 * g + i] = as_f32(dw);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < KD; ++s) {
+            const u32x4 a = lds_read_16B(st, G::Q_OFF + r_off[s] + qb * 32 * C::ROW);
+            s_ = E::mfma(a, kf[s], s_);
+            const u32x4 b = lds_read_16B(st, G::DO_OFF + r_off[s] + qb * 32 * C::ROW);
+            dp = E::mfma(b, vf[s], dp);
+        }
+        // ---- P = exp2((S - L/scale) c), dS = P (dP - D) ----------------------------------------------------
+        uint32_t keep = 0xffffu;   // bit 4g+i: query qbase + 8g + 4hh + i keeps my key
+        if (DROP) keep = dropout_keep_collane(rng, p.drop_thr, (uint32_t)qbase, (uint32_t)my_key, hh);
+        // register r holds query qbase + (r & 3) + 8 (r >> 2) + 4 hh: dead iff that is before my key (causal), past
+        // the sequence, or my key does not exist -> two per-lane limits against compile-time constants
+        int lim_lo = 0, lim_hi = 64;
+        if (kEdge) {
+            lim_lo = p.causal ? my_key - qbase - 4 * hh : 0;
+            lim_hi = seq_q - qbase - 4 * hh;
+            if (my_key >= seq_k) lim_hi = 0;
+        }
+        u32x4 pf[2], dsf[2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float pe[4], de[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * g + i;
+                const float pv = fast_exp2(s_[r] * c2);
+                if (DROP) {
+                    const float z = ((keep >> r) & 1u) ? p.drop_scale : 0.f;
+                    pe[i] = pv * z;
+                    de[i] = pv * fmaf(dp[r], z, dneg[r]);
+                } else {
+                    pe[i] = pv;
+                    de[i] = pv * dp[r];
+                }
+                if (kEdge) {
+                    // selects, not multiplies: the statistics of rows past the sequence are uninitialised (maybe NaN)
+                    const int c = i + 8 * g;
+                    const bool dead = c < lim_lo || c >= lim_hi;
+                    pe[i] = dead ? 0.f : pe[i];
+                    de[i] = dead ? 0.f : de[i];
+                }
+            }
+            // regs 8*ks .. 8*ks+7 are the B operand of K-step ks (queries {0..3, 8..11} + 4hh + 16ks)
+            pf[g >> 1][(g & 1) * 2 + 0] = E::pack2(pe[0], pe[1]);
+            pf[g >> 1][(g & 1) * 2 + 1] = E::pack2(pe[2], pe[3]);
+            dsf[g >> 1][(g & 1) * 2 + 0] = E::pack2(de[0], de[1]);
+            dsf[g >> 1][(g & 1) * 2 + 1] = E::pack2(de[2], de[3]);
+        }
+        // ---- dV^T += dO^T P ; dK^T += Q^T dS   (contraction over the 32 queries) -------------------
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int rows = (qb * 32 + ks * 16) * C::ROW;
+#pragma unroll
+            for (int n = 0; n < NV; ++n) {
+                const u32x2 lo = lds_read_tr16_8B(st, G::DO_OFF + t_off[n][0] + rows);
+                const u32x2 hi = lds_read_tr16_8B(st, G::DO_OFF + t_off[n][1] + rows);
+                dv[n] = E::mfma(u32x4{lo[0], lo[1], hi[0], hi[1]}, pf[ks], dv[n]);
+                const u32x2 lo2 = lds_read_tr16_8B(st, G::Q_OFF + t_off[n][0] + rows);
+                const u32x2 hi2 = lds_read_tr16_8B(st, G::Q_OFF + t_off[n][1] + rows);
+                dk[n] = E::mfma(u32x4{lo2[0], lo2[1], hi2[0], hi2[1]}, dsf[ks], dk[n]);
+            }
+        }
+    };
+
+
+    int g_cmp = 0;
+    auto step_begin = [&]() -> const char * {
+        wait_vmcnt<0>();                  // my share of the current tile has landed ...
+        __builtin_amdgcn_s_barrier();     // ... and everybody's; the other slot was read during the previous step
+        issue_next();
+        const char *st = smem + (g_cmp & 1) * G::STAGE;
+        ++g_cmp;
+        return st;
+    };
+    auto edge_tile = [&](int qt) {
+        const char *st = step_begin();
+        if (!wave_has_keys) return;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const int qbase = qt * C::BT + qb * 32;
+            if (qbase >= seq_q) continue;
+            if (p.causal && qbase + 31 < key0) continue;     // every query is before my first key
+            sub_block(st, qt, qb, std::true_type{});
+        }
+    };
+    auto clean_tile = [&](int qt) {
+        const char *st = step_begin();
+        sub_block(st, qt, 0, std::false_type{});
+        sub_block(st, qt, 1, std::false_type{});
+    };
+
+    issue_next();
+    int first_pass = pass_exists(kts[0]) ? 0 : 1;
+    if (pass_exists(kts[first_pass])) request_fragments(kts[first_pass]);
+    for (int ps = first_pass; ps < 2; ++ps) {
+        const int kt = kts[ps];
+        if (!pass_exists(kt)) continue;
+        key0 = kt * 128 + wave * 32;
+        my_key = key0 + l31;
+        wave_has_keys = key0 < seq_k;
+        const int qt_begin = pass_first(kt);
+#pragma unroll
+        for (int s = 0; s < KD; ++s) { settle(kf[s]); settle(vf[s]); }   // see bp_common.h: no vmcnt(0) in the loop
+#pragma unroll
+        for (int n = 0; n < NV; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dk[n][r] = 0.f; dv[n][r] = 0.f; }
+
+        int clean_begin = nqt, clean_end = nqt;
+        if (wave_has_keys && key0 + 32 <= seq_k) {
+            clean_begin = p.causal ? max(qt_begin, (key0 + 31 + C::BT) / C::BT) : qt_begin;
+            clean_end = seq_q / C::BT;
+        }
+        clean_begin = min(clean_begin, nqt);
+        clean_end = min(max(clean_end, clean_begin), nqt);
+        int qt = qt_begin;
+        for (; qt < clean_begin; ++qt) edge_tile(qt);
+        for (; qt < clean_end; ++qt) clean_tile(qt);
+        for (; qt < nqt; ++qt) edge_tile(qt);
+
+        // epilogue values out of the accumulators first (the stores below then overlap the next pass's fragment loads)
+        const int key_row = min(my_key, seq_k - 1);
+        uint16_t *dkg = reinterpret_cast<uint16_t *>(p.dk) + (si.k_row0 + key_row) * p.dk_rs + (int64_t)head * p.dk_hs;
+        uint16_t *dvg = reinterpret_cast<uint16_t *>(p.dv) + (si.k_row0 + key_row) * p.dv_rs + (int64_t)head * p.dv_hs;
+        const int d_lim = (wave_has_keys && my_key < seq_k) ? p.d : 0;   // lanes past the sequence exchange, but store nothing
+        if (ps == 0 && pass_exists(kts[1])) request_fragments(kts[1]);
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            store_block16<E, (KD <= 4)>(dkg, dk[n], p.scale, n, hh, d_lim);
+            store_block16<E, (KD <= 4)>(dvg, dv[n], 1.f, n, hh, d_lim);
+        }
+    }
+}
+
+template <class ET, int KD, bool FULLD, bool DROP>
+BP_DEV void flash_bwd_dq_chain(const FlashBwdParams p, char *smem, const uint32_t lds0, const int bh, const int qt_a,
+                                 const int qt_b) {
+    using C = BwdCfg<KD>;
+    using E = Elem<ET>;
+    constexpr int NV = C::NV;
+    constexpr int K_OFF = 0, V_OFF = C::TILE, STAGE = 2 * C::TILE;
+    static_assert(C::NSTAGE == 2, "the chained stream is written for the 2-slot ring");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int hh = lane >> 5;
+
+    const int batch = bh / p.h;
+    const int head = bh - batch * p.h;
+    const SeqInfo si = seq_info(p, batch);
+    const int seq_q = si.seq_q, seq_k = si.seq_k;
+
+    const uint16_t *qg = reinterpret_cast<const uint16_t *>(p.q) + si.q_row0 * p.q_rs + (int64_t)head * p.q_hs;
+    const uint16_t *dog = reinterpret_cast<const uint16_t *>(p.dout) + si.q_row0 * p.do_rs + (int64_t)head * p.do_hs;
+    const uint16_t *kg = reinterpret_cast<const uint16_t *>(p.k) + si.k_row0 * p.k_rs + (int64_t)head * p.k_hs;
+    const uint16_t *vg = reinterpret_cast<const uint16_t *>(p.v) + si.k_row0 * p.v_rs + (int64_t)head * p.v_hs;
+    const uint16_t *outg = reinterpret_cast<const uint16_t *>(p.out) + si.q_row0 * p.o_rs + (int64_t)head * p.o_hs;
+    const float c2 = p.scale * kLog2e;
+
+    auto pass_exists = [&](int qt_) { return qt_ >= 0 && qt_ * 128 < seq_q; };
+    auto pass_tiles = [&](int qt_) {
+        if (!pass_exists(qt_)) return 0;
+        const int k_end = p.causal ? min(seq_k, qt_ * 128 + 128) : seq_k;
+        return (k_end + C::BT - 1) / C::BT;
+    };
+    const int qts[2] = {qt_a, qt_b};
+
+    if (!FULLD) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (int off = tid * 16; off < C::NSTAGE * STAGE; off += C::NT * 16) lds_write_16B(smem, off, z);
+        __syncthreads();
+    }
+    DropoutStream rng = {0u, 0u};
+    if (DROP) rng = dropout_stream(p.rng_state, (uint32_t)bh);
+
+    // ---- DMA ---------------------------------------------------------------------------------------------
+    const int kb_partial = (seq_k % C::BT) != 0 ? seq_k / C::BT : -1;
+    const int last_row = seq_k - 1 - (seq_k / C::BT) * C::BT;
+    uint32_t k_voff[C::DMA], v_voff[C::DMA], k_voff_p[C::DMA], v_voff_p[C::DMA];
+    bool piece_live[C::DMA];
+#pragma unroll
+    for (int j = 0; j < C::DMA; ++j) {
+        int row, col;
+        piece<C>(wave, lane, j, row, col);
+        piece_live[j] = FULLD || col < p.d;
+        k_voff[j] = (uint32_t)(row * p.k_rs + col) * 2u;
+        v_voff[j] = (uint32_t)(row * p.v_rs + col) * 2u;
+        k_voff_p[j] = (uint32_t)(min(row, last_row) * p.k_rs + col) * 2u;
+        v_voff_p[j] = (uint32_t)(min(row, last_row) * p.v_rs + col) * 2u;
+    }
+    const int64_t k_tile_stride = (int64_t)C::BT * p.k_rs, v_tile_stride = (int64_t)C::BT * p.v_rs;
+    int iss_pass = 0, iss_left = pass_tiles(qts[0]), iss_kb = 0, g_iss = 0;
+    if (iss_left == 0) { iss_pass = 1; iss_left = pass_tiles(qts[1]); }
+    const uint16_t *kt_ptr = kg, *vt_ptr = vg;
+    auto issue_next = [&]() {
+        if (iss_left == 0) return;
+        const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + (g_iss & 1) * STAGE);
+        const bool partial = iss_kb == kb_partial;
+#pragma unroll
+        for (int j = 0; j < C::DMA; ++j)
+            if (piece_live[j]) {
+                dma16_s(kt_ptr, partial ? k_voff_p[j] : k_voff[j],
+                        __builtin_amdgcn_readfirstlane(st + K_OFF + (wave * C::DMA + j) * 1024));
+                dma16_s(vt_ptr, partial ? v_voff_p[j] : v_voff[j],
+                        __builtin_amdgcn_readfirstlane(st + V_OFF + (wave * C::DMA + j) * 1024));
+            }
+        ++g_iss; ++iss_kb; --iss_left;
+        kt_ptr += k_tile_stride;
+        vt_ptr += v_tile_stride;
+        if (iss_left == 0 && iss_pass == 0) {
+            iss_pass = 1; iss_left = pass_tiles(qts[1]); iss_kb = 0;
+            kt_ptr = kg; vt_ptr = vg;
+        }
+    };
+
+    int r_off[KD];
+#pragma unroll
+    for (int s = 0; s < KD; ++s) r_off[s] = row_read_off<C>(l31, hh, s);
+    int t_off[NV][2];
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+        t_off[n][0] = tr_read_off<C>(lane, n, 0);
+        t_off[n][1] = tr_read_off<C>(lane, n, 1);
+    }
+
+    // ---- per-pass state ---------------------------------------------------------------------------------
+    int q0 = 0, my_q = 0;
+    bool wave_has_rows = false;
+    u32x4 qf[KD], dof[KD], of[KD];
+    float lse_row = 0.f, lneg = 0.f, dneg = 0.f, lneg2 = 0.f;
+    f32x16 c_d, dq[NV];
+    auto request_fragments = [&](int qt_) {
+        const int q = min(qt_ * 128 + wave * 32 + l31, seq_q - 1);
+#pragma unroll
+        for (int s = 0; s < KD; ++s) {
+            const int col = 16 * s + 8 * hh;
+            u32x4 a = {0u, 0u, 0u, 0u}, b = {0u, 0u, 0u, 0u}, o = {0u, 0u, 0u, 0u};
+            if (FULLD || col < p.d) {
+                a = ld_global_16B(qg + (int64_t)q * p.q_rs + col);
+                b = ld_global_16B(dog + (int64_t)q * p.do_rs + col);
+                o = ld_global_16B(outg + (int64_t)q * p.o_rs + col);
+            }
+            qf[s] = a;
+            dof[s] = b;
+            of[s] = o;
+        }
+        lse_row = p.lse[((int64_t)batch * p.h + head) * p.lse_stride + q];
+    };
+
+    // one 32-key sub-block kk of the tile in `st`
+    auto sub_block = [&](const char *st, int kb, int kk, auto EDGE) {
+        constexpr bool kEdge = decltype(EDGE)::value;
+        const int kbase = kb * C::BT + kk * 32;
+        // S^T = K Q^T and dP^T = V dO^T - D : rows = keys (registers), column = my query
+        f32x16 st_, dpt = c_d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st_[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KD; ++s) {
+            const u32x4 a = lds_read_16B(st, K_OFF + r_off[s] + kk * 32 * C::ROW);
+            st_ = E::mfma(a, qf[s], st_);
+            const u32x4 b = lds_read_16B(st, V_OFF + r_off[s] + kk * 32 * C::ROW);
+            dpt = E::mfma(b, dof[s], dpt);
+        }
+        uint32_t keep = 0xffffu;   // bit 4g+i: my query keeps key kbase + 8g + 4hh + i
+        if (DROP) keep = dropout_keep_rowlane(rng, p.drop_thr, (uint32_t)my_q, (uint32_t)kbase, hh);
+        // register r holds key kbase + (r & 3) + 8 (r >> 2) + 4 hh: dead iff beyond the last key my row may see
+        int lim = 64;
+        if (kEdge) {
+            int last = seq_k - 1;
+            if (p.causal) last = min(last, my_q);
+            lim = last - kbase - 4 * hh;
+        }
+        u32x4 dsf[2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float de[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * g + i;
+                const float pv = fast_exp2(fmaf(st_[r], c2, lneg2));
+                if (DROP) {
+                    const float z = ((keep >> r) & 1u) ? p.drop_scale : 0.f;
+                    de[i] = pv * fmaf(dpt[r], z, dneg);
+                } else {
+                    de[i] = pv * dpt[r];
+                }
+                if (kEdge) de[i] = (i + 8 * g > lim) ? 0.f : de[i];
+            }
+            dsf[g >> 1][(g & 1) * 2 + 0] = E::pack2(de[0], de[1]);
+            dsf[g >> 1][(g & 1) * 2 + 1] = E::pack2(de[2], de[3]);
+        }
+        // dQ^T += K^T dS^T  (contraction over the 32 keys)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int rows = (kk * 32 + ks * 16) * C::ROW;
+#pragma unroll
+            for (int n = 0; n < NV; ++n) {
+                const u32x2 lo = lds_read_tr16_8B(st, K_OFF + t_off[n][0] + rows);
+                const u32x2 hi = lds_read_tr16_8B(st, K_OFF + t_off[n][1] + rows);
+                dq[n] = E::mfma(u32x4{lo[0], lo[1], hi[0], hi[1]}, dsf[ks], dq[n]);
+            }
+        }
+    };
+
+
+    int g_cmp = 0;
+    auto step_begin = [&]() -> const char * {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        issue_next();
+        const char *st = smem + (g_cmp & 1) * STAGE;
+        ++g_cmp;
+        return st;
+    };
+
+    issue_next();
+    int first_pass = pass_exists(qts[0]) ? 0 : 1;
+    if (pass_exists(qts[first_pass])) request_fragments(qts[first_pass]);
+    for (int ps = first_pass; ps < 2; ++ps) {
+        const int qt = qts[ps];
+        if (!pass_exists(qt)) continue;
+        q0 = qt * 128 + wave * 32;
+        my_q = q0 + l31;
+        wave_has_rows = q0 < seq_q;
+        const int nkb = pass_tiles(qt);
+        {   // D of my row from the dO and O fragments; publish -D and -L / scale for the dkdv kernel
+            float part = 0.f;
+#pragma unroll
+            for (int s = 0; s < KD; ++s) {
+                const u32x4 b = dof[s], o = of[s];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t bw = b[i], ow = o[i];   // by-value copies (bp_common.h, as_f32)
+                    part = fmaf(E::lo_f32(bw), E::lo_f32(ow), part);
+                    part = fmaf(E::hi_f32(bw), E::hi_f32(ow), part);
+                }
+            }
+            lneg = lse_row == -INFINITY ? 0.f : -lse_row / p.scale;
+            dneg = -xhalf_sum(part);
+            if (hh == 0 && wave_has_rows && my_q < seq_q) {
+                float *st = stats_row(p, batch, head);
+                st[my_q] = dneg;
+                st[p.lse_stride + my_q] = lneg;
+            }
+#pragma unroll
+            for (int s = 0; s < KD; ++s) { settle(qf[s]); settle(dof[s]); }
+            settle(lneg); settle(dneg);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c_d[r] = DROP ? 0.f : dneg;
+        lneg2 = lneg * c2;
+#pragma unroll
+        for (int n = 0; n < NV; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[n][r] = 0.f;
+
+        const int my_nkb = !wave_has_rows ? 0 : p.causal ? min(nkb, (q0 + 31) / C::BT + 1) : nkb;
+        const int my_clean_end = !wave_has_rows ? 0 : p.causal ? min(seq_k / C::BT, (q0 + 1) / C::BT) : seq_k / C::BT;
+        int kb = 0;
+        for (; kb < min(my_clean_end, nkb); ++kb) {
+            const char *st = step_begin();
+            sub_block(st, kb, 0, std::false_type{});
+            sub_block(st, kb, 1, std::false_type{});
+        }
+        for (; kb < nkb; ++kb) {
+            const char *st = step_begin();
+            if (kb >= my_nkb) continue;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int kbase = kb * C::BT + kk * 32;
+                if (kbase >= seq_k) continue;
+                if (p.causal && kbase > q0 + 31) continue;
+                sub_block(st, kb, kk, std::true_type{});
+            }
+        }
+
+        uint16_t *dqg = reinterpret_cast<uint16_t *>(p.dq) + (si.q_row0 + min(my_q, seq_q - 1)) * p.dq_rs + (int64_t)head * p.dq_hs;
+        const int d_lim = (wave_has_rows && my_q < seq_q) ? p.d : 0;
+        if (ps == 0 && pass_exists(qts[1])) request_fragments(qts[1]);
+#pragma unroll
+        for (int n = 0; n < NV; ++n) store_block16<E, (KD <= 4)>(dqg, dq[n], p.scale, n, hh, d_lim);
+    }
+}
+
 // Kernels: a causal workgroup takes the heaviest remaining tile and the lightest of its (sample, head) -- tiles t
 // and n-1-t -- so that every workgroup carries the same work (in-order round-robin dispatch, see flash_fwd_dma.hip).
 // (the dropout variants spill 500+ registers at three waves per SIMD: they keep two)
@@ -738,6 +1271,12 @@ __global__ __launch_bounds__(256, BP_BWD_DKDV_MINWAVES(KD, DROP)) void flash_bwd
     if (!xcd_map(blockIdx.x, p.b * p.h, pair ? (n + 1) / 2 : n, bh, slot)) return;   // key tile 0 = most work
     const int other = n - 1 - slot;
     const int npass = (pair && other != slot) ? 2 : 1;
+#if BP_BWD_CHAIN
+    if constexpr (KD <= 4) {
+        flash_bwd_dkdv_chain<ET, KD, FULLD, DROP>(p, smem, lds0, bh, slot, npass == 2 ? other : -1);
+        return;
+    }
+#endif
     for (int pass = 0; pass < npass; ++pass) {
         if (pass) __syncthreads();
         flash_bwd_dkdv_tile<ET, KD, FULLD, DROP>(p, smem, lds0, bh, pass ? other : slot, pass);
@@ -760,6 +1299,12 @@ __global__ __launch_bounds__(256, BP_BWD_DQ_MINWAVES(KD)) void flash_bwd_dq_kern
     if (!xcd_map(blockIdx.x, p.b * p.h, pair ? (n + 1) / 2 : n, bh, slot)) return;
     const int heavy = n - 1 - slot;
     const int npass = (pair && heavy != slot) ? 2 : 1;
+#if BP_BWD_CHAIN
+    if constexpr (KD <= 4) {
+        flash_bwd_dq_chain<ET, KD, FULLD, DROP>(p, smem, lds0, bh, heavy, npass == 2 ? slot : -1);
+        return;
+    }
+#endif
     for (int pass = 0; pass < npass; ++pass) {
         if (pass) __syncthreads();
         flash_bwd_dq_tile<ET, KD, FULLD, DROP>(p, smem, lds0, bh, pass ? slot : heavy, pass);
