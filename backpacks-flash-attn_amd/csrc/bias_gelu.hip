@@ -9,7 +9,7 @@
 //   column_sum      dbias[c] = sum_r g[r, c]             (bias gradient of a plain dense layer, `linear_bias_wgrad`)
 //
 // gelu_tanh is GPT-2's `gelu_new`: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))), the approximation the reference's
-// epilogue and `F.gelu(approximate='tanh')` use.  tanh(u) = 1 - 2 / (1 + e^(2u)) through v_exp_f32 / v_rcp_f32.
+// epilogue and `F.gelu(approximate='tanh')` use.  tanh(u) = 1 - 2 / (1 + e^(2u)) through v_exp_f32 / v_rcp_f32 (gelu_r).
 //
 // Layout: rows x cols 16-bit, unit column stride, cols % 8 == 0; a thread owns 8 consecutive columns (one 16-byte
 // access per row).  The column sums are deterministic, two stages, no atomics: workgroup (chunk of 512 columns, slice)
@@ -26,18 +26,21 @@ namespace {
 constexpr float kGeluA = 0.7978845608028654f;   // sqrt(2 / pi)
 constexpr float kGeluB = 0.044715f;
 
-// tanh of the GELU argument, from x
-BP_DEV float gelu_tanh_arg(float x) {
-    const float u = kGeluA * x * fmaf(kGeluB * x, x, 1.f);
-    // tanh(u) = 1 - 2 / (1 + exp(2u)); exp2 overflow -> inf -> rcp 0 -> 1, underflow -> 0 -> -1: no clamp needed
-    const float e = fast_exp2(u * (2.f * kLog2e));
-    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + e);
+// With r = 1 / (1 + e^(2u)), u = sqrt(2/pi) x (1 + 0.044715 x^2):  tanh(u) = 1 - 2r, so
+//   gelu(x)  = 0.5 x (1 + tanh u)                        = x (1 - r)
+//   gelu'(x) = 0.5 (1 + tanh u) + 0.5 x (1 - tanh^2 u) u' = (1 - r) (1 + 2 x r u'),   u' = sqrt(2/pi) (1 + 3 * 0.044715 x^2)
+// (1 - tanh^2 = 4 r (1 - r)).  One v_exp_f32 and one v_rcp_f32 per element; exp2 overflow -> inf -> r = 0 -> gelu = x,
+// gelu' = 1; underflow -> r = 1 -> both 0: no clamp needed.
+BP_DEV float gelu_r(float x, float x2) {
+    const float u2 = (x * fmaf(kGeluB, x2, 1.f)) * (2.f * kGeluA * kLog2e);
+    return __builtin_amdgcn_rcpf(1.f + fast_exp2(u2));
 }
-BP_DEV float gelu_fwd(float x) { return 0.5f * x * (1.f + gelu_tanh_arg(x)); }
+BP_DEV float gelu_fwd(float x) { return x * (1.f - gelu_r(x, x * x)); }
 BP_DEV float gelu_grad(float x) {
-    const float t = gelu_tanh_arg(x);
-    const float du = kGeluA * fmaf(3.f * kGeluB * x, x, 1.f);
-    return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * du;
+    const float x2 = x * x;
+    const float r = gelu_r(x, x2);
+    const float du2 = fmaf(6.f * kGeluA * kGeluB, x2, 2.f * kGeluA);   // 2 u'
+    return (1.f - r) * fmaf(x * r, du2, 1.f);
 }
 
 template <class ET> BP_DEV void unpack8(const u32x4 w, float (&v)[8]) {
