@@ -233,6 +233,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-threads', type=int, default=None)
     ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="'nccl' (= RCCL, one rank per GPU) for every real run; 'gloo' moves the same collectives "
+                         "through host memory and lets several ranks share one GPU -- the test-suite's world-size-2 run "
+                         "on the one leased GPU")
     ap.add_argument('--graph', action='store_true',
                     help='capture one forward in a HIP graph and replay it per step (launch-bound small '
                          'configs; per-kernel events are not taken in this mode)')
@@ -244,13 +248,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
+    if args.dist_backend == 'gloo':      # test-suite only: ranks may share a device
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     dist = None
     # under torch.distributed.run (any world size, 1 included: the launch path is then the one the N-GPU runs take)
     if world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ):
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=device)   # 'nccl' is RCCL on ROCm
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)   # 'nccl' is RCCL on ROCm
+        else:
+            dist.init_process_group('gloo')
 
     import bp_hip
     bp_hip.lib()   # fail loudly if the HIP extension is missing -- no fallback path exists

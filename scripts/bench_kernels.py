@@ -41,6 +41,8 @@ def main():
     ap.add_argument('--dtype', default='bf16')
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--noncausal', action='store_true')
+    ap.add_argument('--content-layout', default='bskd', choices=['bskd', 'bksd'],
+                    help="storage order of the content tensor handed to the mix kernel (a strided view either way)")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == 'bf16' else torch.float16
     dev = 'cuda'
@@ -77,11 +79,14 @@ def main():
         res.append(dict(kernel='sense_lse', ms=ms, tflops=2 * pairs * d * B / ms / 1e9,
                         gbps=(4 * S * d + 4 * K * S) * B / ms / 1e6))
     if 'mix' in which:
-        c = torch.randn(B, S, K, d, device=dev).to(dt)
+        if a.content_layout == 'bksd':   # sense-major storage: a (sense, key) row is 2*d bytes from the next key's
+            c = torch.randn(B, K, S, d, device=dev).to(dt).transpose(1, 2)
+        else:
+            c = torch.randn(B, S, K, d, device=dev).to(dt)
         lse = bp_hip.sense_lse(qk)
         out = torch.empty(B, S, d, device=dev, dtype=dt)
         ms = timeit(lambda: bp_hip.sense_mix(qk, c, out=out, lse=lse), a.iters)
-        res.append(dict(kernel='sense_mix', ms=ms, tflops=2 * pairs * d * (1 + K) * B / ms / 1e9,
+        res.append(dict(kernel='sense_mix', layout=a.content_layout, ms=ms, tflops=2 * pairs * d * (1 + K) * B / ms / 1e9,
                         gbps=(4 + 2 * K + 2) * S * d * B / ms / 1e6))
     if 'alpha' in which:
         Ba = min(B, 64)     # (Ba, k, S, S) 16-bit: 2.1 GB at 64 x 16 x 1024^2 -- far past the 256 MiB Infinity Cache

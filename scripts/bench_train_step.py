@@ -30,15 +30,22 @@ def main():
     ap.add_argument('--model', default='small')
     ap.add_argument('--dropout', type=float, default=0.1)
     ap.add_argument('--pure-bf16', action='store_true')
+    ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="'gloo': the collectives go through host memory and ranks may share a GPU (test-suite only)")
     a = ap.parse_args()
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    if a.dist_backend == 'gloo':
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     ddp = world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ)   # under torch.distributed.run
     if ddp:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if a.dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group('gloo')
     from bench import MODELS
     from flash_attn.losses.cross_entropy import CrossEntropyLoss
     from src.models.backpack import BackpackConfig, BackpackLMHeadModel
@@ -90,7 +97,7 @@ def main():
                           'grad_allreduce_bytes': sum(p.numel() * p.element_size() for p in model.parameters()),
                           'loss': round(float(loss.detach()), 4),
                           'peak_mem_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
-                          'launch': 'torch.distributed.run, DDP over nccl (RCCL)' if ddp else 'single process'}))
+                          'launch': ('torch.distributed.run, DDP over ' + ('nccl (RCCL)' if a.dist_backend == 'nccl' else 'gloo')) if ddp else 'single process'}))
     if ddp:
         dist.barrier()
         dist.destroy_process_group()
