@@ -124,6 +124,24 @@ BP_DEV u32x2 lds_read_tr16_8B(const char *smem, int off) {
     return __builtin_bit_cast(u32x2, v);
 }
 
+// A run of N MFMAs whose LDS operands are requested two MFMAs ahead.  hipcc's own order is "read, s_waitcnt
+// lgkmcnt(0), MFMA" per MFMA -- a full LDS round trip in front of each, 75-85 clocks per MFMA where the pipe needs 32
+// (sense-mix timeline, r03_aa).  LDS reads are memory operations and keep their program order relative to volatile
+// asm, so the empty pins hold fetch(i + 2) in front of MFMA i; the compiler's own counted lgkmcnt waits follow.
+//   fetch(i) -> u32x4 operand of MFMA i;  use(i, a): the MFMA, followed by a pin on the accumulator it wrote.
+template <int N, class Fetch, class Use> BP_DEV void mfma_stream(Fetch &&fetch, Use &&use) {
+    u32x4 a0 = fetch(0), a1 = fetch(N > 1 ? 1 : 0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        u32x4 a2 = a0;
+        if (i + 2 < N) a2 = fetch(i + 2);
+        asm volatile("" : "+v"(a0));
+        use(i, a0);
+        a0 = a1;
+        a1 = a2;
+    }
+}
+
 // Byte offset of 16-B chunk `ch` of row `row` in a V / content tile whose rows hold NV 64-byte
 // chunks.  ds_read_b64_tr_b16 serves 32 lanes at once = 4 consecutive rows x 64 B; the XOR on the
 // 64-B chunk index puts those 4 row segments in the 4 different quarters of the 64 banks.

@@ -35,6 +35,21 @@
 
 namespace bp {
 
+// Development builds only (-DBP_MIX_PROFILE, scripts/probes/mix_timeline): every wave adds up the s_memtime ticks its
+// clean steps spend in each phase; never in the shipped library.
+#ifdef BP_MIX_PROFILE
+__device__ unsigned long long g_mix_prof[256][8][8];   // [workgroup][wave][phase 0..5, 6 = clean steps, 7 = job ticks]
+#define MIX_TICK(var) const unsigned long long var = __builtin_readcyclecounter()
+#define MIX_ADD(k, expr) prof[k] += (expr)
+#else
+#define MIX_TICK(var) do { } while (0)
+#define MIX_ADD(k, expr) do { } while (0)
+#endif
+
+#ifndef BP_MIX_X_PRIO
+#define BP_MIX_X_PRIO 3
+#endif
+
 template <int KD, bool WEIGHTED = false>
 struct MixDmaCfg {
     static constexpr int BM = 256, BK = 64, NB = 8, BNC = 256, NT = 512, NWAVE = 8, NSTAGE = 3;
@@ -130,6 +145,9 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
         return -1;
     };
 
+#ifdef BP_MIX_PROFILE
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (;;) {
         __syncthreads();   // every wave is done with the previous job's ring (and has read its job word)
         if (tid == 0) *reinterpret_cast<int *>(smem + C::JOB_OFF) = next_job();
@@ -137,6 +155,7 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
         const int job = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(smem + C::JOB_OFF));
         if (job < 0) break;
         const int grp = job >> 8, qt = job & 255;
+        MIX_TICK(job_t0);
         const int batch = grp / p.n_chunks;
         const int chunk = grp - batch * p.n_chunks;
         const int col_base = chunk * C::BNC;
@@ -176,24 +195,28 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
             c_voff_p[j] = (uint32_t)(min(c_row[j], last_row) * p.c_rs + col) * 2u;
         }
 
-        // DMA pieces of pipeline step (l, kb) into ring slot `slot`; `pieces` selects a subset (bit j)
-        auto issue = [&](int l, int kb, int slot, uint32_t pieces) {
+        // DMA pieces of the tile two steps ahead, (l2, kb2), into ring slot `slot`; `pieces` selects a subset (bit j).
+        // The tile's base pointers kt2 / ct2 are carried and advanced on the scalar unit once per step (advance2 below):
+        // recomputing them from (l, kb) in each of a step's calls cost ~120 SALU instructions per step.
+        int l2 = 0, kb2 = 0;                     // (sense, tile) of step + 2
+        const uint16_t *ks2 = kg, *cs2 = cg;     // key / content base of sense l2
+        const uint16_t *kt2 = kg, *ct2 = cg;     // ... of tile kb2 in it
+        const int64_t k_tile_step = (int64_t)C::BK * p.qk_rs, c_tile_step = (int64_t)C::BK * p.c_rs;
+        auto issue = [&](int, int, int slot, uint32_t pieces) {
             const uint32_t stage_off = lds0 + slot * C::STAGE;
-            const uint16_t *kt = kg + (int64_t)l * p.qk_ss + (int64_t)kb * C::BK * p.qk_rs;
-            const uint16_t *ct = cg + (int64_t)l * p.c_ss + (int64_t)kb * C::BK * p.c_rs;
-            const bool partial = kb == kb_partial;
+            const bool partial = kb2 == kb_partial;
 #pragma unroll
             for (int j = 0; j < C::K_DMA; ++j)
                 if ((pieces >> j) & 1u)
-                    dma16_s(kt, partial ? k_voff_p[j] : k_voff[j], stage_off + (wave * C::K_DMA + j) * 1024);
+                    dma16_s(kt2, partial ? k_voff_p[j] : k_voff[j], stage_off + (wave * C::K_DMA + j) * 1024);
 #pragma unroll
             for (int j = 0; j < C::C_DMA; ++j)
                 if ((pieces >> (C::K_DMA + j)) & 1u)
                     // the content stream is read once per job: non-temporal (-1.6 % at B=64, r02_p)
-                    dma16_s_nt(ct, partial ? c_voff_p[j] : c_voff[j], stage_off + C::KTILE + (wave * C::C_DMA + j) * 1024);
+                    dma16_s_nt(ct2, partial ? c_voff_p[j] : c_voff[j], stage_off + C::KTILE + (wave * C::C_DMA + j) * 1024);
             if (WEIGHTED && ((pieces >> (C::K_DMA + C::C_DMA)) & 1u)) {
                 // key weights of this (sense, tile): lane i fetches w[key0 + i] into the wave's own 256-B slot
-                const float *src = p.kw + batch * p.kw_bs + (int64_t)l * p.kw_ss + min(kb * C::BK + lane, S - 1);
+                const float *src = p.kw + batch * p.kw_bs + (int64_t)l2 * p.kw_ss + min(kb2 * C::BK + lane, S - 1);
                 dma4(src, stage_off + C::KTILE + C::CTILE + wave * 256);
             }
         };
@@ -274,29 +297,39 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
             const u32x2 hi = lds_read_tr16_8B(smem, c_read_off[n & 3] + (n >> 2) * 256 + rows + 8 * C::CROW);
             return u32x4{lo[0], lo[1], hi[0], hi[1]};
         };
-        // O^T += C^T P^T for 16 keys (ks) of half kk
-        auto pv = [&](int stage, int kk, int ks, const u32x4 &pfk) {
-            const int rows = stage + C::KTILE + (kk * 32 + ks * 16) * C::CROW;
-#pragma unroll
-            for (int n = 0; n < C::NB; ++n)
-                if (FULL || n < nb_live) acc[n] = E::mfma(c_operand(rows, n), pfk, acc[n]);
+        // O^T += C^T P^T over N consecutive 16-key steps (pk[0..N-1]) from key row `row0` of the tile at `stage`: 8 N MFMAs
+        // as ONE operand stream with the C^T operand of MFMA i + 2 requested before MFMA i issues (mfma_stream,
+        // bp_common.h) -- hipcc on its own puts "2 ds_read, s_waitcnt lgkmcnt(0)" in front of every MFMA: 75-85 clocks
+        // per MFMA where the pipe needs 32 (r03_aa/ab timelines).  `mid(i)` runs behind MFMA i (DMA issue points).
+        auto pv_stream = [&](int stage, int row0, const auto &pk, auto &&mid) {
+            constexpr int N = sizeof(pk) / sizeof(pk[0]) * C::NB;
+            const int base = stage + C::KTILE + row0 * C::CROW;
+            mfma_stream<N>([&](int i) { return c_operand(base + (i >> 3) * 16 * C::CROW, i & 7); },
+                           [&](int i, const u32x4 &a) {
+                               if (FULL || (i & 7) < nb_live) acc[i & 7] = E::mfma(a, pk[i >> 3], acc[i & 7]);
+                               asm volatile("" : "+v"(acc[i & 7]));
+                               mid(i);
+                           });
         };
 
-        // ---- steady-state step: every row sees every key of the tile; softmax of half 1 under the MFMAs of half 0.
-        // Pure arithmetic is not ordered by source position (nor by sched_barrier, which only freezes the order
-        // instruction selection happened to pick), and hipcc on its own issues all VALU first and the MFMAs back to
-        // back.  So the interleave is pinned with EMPTY volatile asm statements: each one "rewrites" a value, asm
-        // volatile statements keep their program order, hence whatever produces the value sits before its pin and
-        // whatever consumes the pinned value after it.
-        auto clean_step = [&](int stage, int l2, int kb2, int slot2) {
-            u32x4 pf0[2], pf1[2];
+        // The step is cut into a vector-heavy half X (S^T of both key halves, softmax of half 0, the first 8 MFMAs of
+        // half 0 with the exponentials of half 1 between them, pack) and a matrix-only half Y (the other 24 MFMAs),
+        // and the two waves of a SIMD (w and w + 4) run them in ANTI-PHASE: waves 4-7 enter the clean loop one barrier
+        // late, so X of one wave always meets Y of the other (see the loop below).  X hands Y three packed operands.
+        u32x4 pfc[3];   // P^T of half 0 keys 16..31, of half 1 keys 0..15 and 16..31
+        auto clean_x = [&](int stage, int l2, int kb2, int slot2, bool dma) {
+            // X is one dependent chain (S^T -> softmax -> first MFMAs), Y a stream of independent MFMAs: without a
+            // priority the older waves 0-3 win every arbitration, and X of waves 4-7 starves behind their Y (2230
+            // clocks against 1360 the other way round, r03_ab timeline)
+            __builtin_amdgcn_s_setprio(BP_MIX_X_PRIO);
+            u32x4 pf0[2];
             {
                 f32x16 st0 = scores(stage, 0);
                 exponentiate(st0);
                 pack(st0, pf0);
             }
             f32x16 st1 = scores(stage, 1);
-            issue(l2, kb2, slot2, 0x01u);
+            if (dma) issue(l2, kb2, slot2, 0x03u);
             // 8 MFMAs of half 0, keys 0..15, each followed by 2 fma + 2 exp of half 1; the C operand of MFMA n+1 is
             // requested before MFMA n issues, so the LDS latency hides behind a full MFMA
             {
@@ -319,28 +352,20 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
                     a = a_next;
                 }
             }
-            issue(l2, kb2, slot2, 0x02u);
-            // 8 MFMAs of half 0, keys 16..31, each followed by one pack of half 1
-            {
-                const int rows = stage + C::KTILE + 16 * C::CROW;
-                u32x4 a = c_operand(rows, 0);
-#pragma unroll
-                for (int n = 0; n < C::NB; ++n) {
-                    u32x4 a_next = a;
-                    if (n + 1 < C::NB) a_next = c_operand(rows, n + 1);
-                    asm volatile("" : "+v"(a));
-                    acc[n] = E::mfma(a, pf0[1], acc[n]);
-                    asm volatile("" : "+v"(acc[n]));
-                    uint32_t w = E::pack2(st1[2 * n], st1[2 * n + 1]);
-                    asm volatile("" : "+v"(w));
-                    pf1[n >> 2][n & 3] = w;
-                    a = a_next;
-                }
-            }
-            issue(l2, kb2, slot2, 0x0cu);
-            pv(stage, 1, 0, pf1[0]);
-            issue(l2, kb2, slot2, kAllPieces & ~0x0fu);
-            pv(stage, 1, 1, pf1[1]);
+            if (dma) issue(l2, kb2, slot2, kAllPieces & ~0x03u);
+            pfc[0] = pf0[1];
+            u32x4 pf1[2];
+            pack(st1, pf1);
+            pfc[1] = pf1[0];
+            pfc[2] = pf1[1];
+            asm volatile("" : "+v"(pfc[0]), "+v"(pfc[1]), "+v"(pfc[2]));   // the packs belong to X, not behind the barrier
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto clean_y = [&](int stage, int l2, int kb2, int slot2, bool dma) {
+            if (dma) issue(l2, kb2, slot2, 0x03u);
+            pv_stream(stage, 16, pfc, [&](int i) {
+                if (i == 11 && dma) issue(l2, kb2, slot2, kAllPieces & ~0x03u);
+            });
         };
 
         // ---- a step that touches the diagonal region (or carries key weights): per-half liveness, masking
@@ -383,11 +408,9 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
                                 pf[ks][i] &= keep;
                             }
                     }
-                    pv(stage, kk, 0, pf[0]);
+                    pv_stream(stage, kk * 32, pf, [](int) {});
                 }
-                issue(l2, kb2, slot2, kk == 0 ? 0x02u : (kAllPieces & ~0x0fu));
-                if (live) pv(stage, kk, 1, pf[1]);
-                if (kk == 0) issue(l2, kb2, slot2, 0x0cu);
+                issue(l2, kb2, slot2, kk == 0 ? 0x0eu : (kAllPieces & ~0x0fu));
             }
         };
 
@@ -396,10 +419,19 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
         // DMA count per step constant so the counted wait below never changes).  The clean and the edge steps
         // of a sense run in two consecutive loops, each with ONE body: the accumulators then never meet at an
         // if/else join (hipcc answers such a join of 128 registers with copies and spills).
-        int l2 = 0, kb2 = 0;                     // (sense, tile) of step + 2
         auto advance2 = [&]() {
-            if (kb2 + 1 < nkb) { ++kb2; }
-            else if (l2 + 1 < p.nsenses) { ++l2; kb2 = 0; }
+            if (kb2 + 1 < nkb) {
+                ++kb2;
+                kt2 += k_tile_step;
+                ct2 += c_tile_step;
+            } else if (l2 + 1 < p.nsenses) {
+                ++l2;
+                kb2 = 0;
+                ks2 += p.qk_ss;
+                cs2 += p.c_ss;
+                kt2 = ks2;
+                ct2 = cs2;
+            }
         };
         issue(0, 0, 0, kAllPieces);
         advance2();
@@ -421,16 +453,48 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
         for (int l = 0; l < p.nsenses; ++l) {
             if (!ASYNC_Q && wave_has_rows) take_q(l);
             const bool more = ASYNC_Q && wave_has_rows && l + 1 < p.nsenses;
-            for (int kb = 0; kb < nkb_clean; ++kb) {
-                step_begin();
-                clean_step(slot * C::STAGE, l2, kb2, slot >= 1 ? slot - 1 : 2);
-                step_end();
+            // Clean steps, two barriers each.  Waves 0-3 run  [bar X bar Y] per tile and one closing barrier; waves 4-7 one
+            // opening barrier and then the same [bar X bar Y]: between any two barriers one wave of a SIMD is in X
+            // (VALU + 14 MFMAs) and the other in Y (24 MFMAs) of the same or the previous tile.  Ring: tile kb + 2 goes
+            // to the slot of tile kb - 1, last read by Y of waves 4-7 in front of the barrier that ends X(kb) of waves
+            // 0-3 -- so every wave issues it right behind that barrier (start of Y for waves 0-3, of X for waves 4-7);
+            // every wave waits for its share of the next tile before each barrier (a no-op on every other one).
+            if (nkb_clean > 0) {
+                const bool late = wave >= C::NWAVE / 2;
+                if (late) step_begin();
+                for (int kb = 0; kb < nkb_clean; ++kb) {
+                    MIX_TICK(t0);
+                    step_begin();
+                    MIX_TICK(t1);
+                    MIX_ADD(0, t1 - t0);
+                    clean_x(slot * C::STAGE, l2, kb2, slot >= 1 ? slot - 1 : 2, late);
+#ifdef BP_MIX_PROFILE
+                    asm volatile("" : "+v"(acc[7]), "+v"(pfc[0]), "+v"(pfc[1]), "+v"(pfc[2]));
+#endif
+                    MIX_TICK(t2);
+                    MIX_ADD(1, t2 - t1);
+                    step_begin();
+                    MIX_TICK(t3);
+                    MIX_ADD(2, t3 - t2);
+                    clean_y(slot * C::STAGE, l2, kb2, slot >= 1 ? slot - 1 : 2, !late);
+#ifdef BP_MIX_PROFILE
+                    asm volatile("" : "+v"(acc[7]));
+#endif
+                    MIX_TICK(t4);
+                    MIX_ADD(3, t4 - t3);
+                    MIX_ADD(6, 1);
+                    step_end();
+                }
+                if (!late) __builtin_amdgcn_s_barrier();
             }
             for (int kb = nkb_clean; kb < nkb; ++kb) {   // (never empty: the diagonal tile is an edge tile)
+                MIX_TICK(e0);
                 step_begin();
                 if (more && kb == nkb - 1) request_q(l + 1);
                 edge_step(slot * C::STAGE, l, kb, l2, kb2, slot >= 1 ? slot - 1 : 2);
                 step_end();
+                MIX_TICK(e1);
+                MIX_ADD(5, e1 - e0);
             }
             if (more) adopt_q();
         }
@@ -450,8 +514,13 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
                     }
                 }
         }
+        MIX_TICK(job_t1);
+        MIX_ADD(7, job_t1 - job_t0);
     }
-
+#ifdef BP_MIX_PROFILE
+    if (lane == 0 && blockIdx.x < 256)
+        for (int k = 0; k < 8; ++k) g_mix_prof[blockIdx.x][wave][k] = prof[k];
+#endif
 }
 
 // Queue state of a persistent launch: one 64-byte record of device memory, zeroed by a one-wave kernel enqueued right in
@@ -532,6 +601,12 @@ static hipError_t launch_et(const MixParams &p, hipStream_t stream) {
         default: return launch_kd<ET, 8>(p, stream);
     }
 }
+
+#ifdef BP_MIX_PROFILE
+extern "C" int bp_dev_mix_prof(unsigned long long *host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_mix_prof), sizeof(g_mix_prof)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // Requires: d_k % 8 == 0, d_out % 8 == 0, all bases 16-byte aligned, all strides multiples of 8, n_qtiles <= 256.
 hipError_t launch_sense_mix_dma(const MixParams &p, int dtype, hipStream_t stream) {
