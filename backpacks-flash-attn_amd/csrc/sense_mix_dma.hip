@@ -323,12 +323,22 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
             // clocks against 1360 the other way round, r03_ab timeline)
             __builtin_amdgcn_s_setprio(BP_MIX_X_PRIO);
             u32x4 pf0[2];
+            f32x16 st1;
             {
-                f32x16 st0 = scores(stage, 0);
+                // S^T of both key halves as one operand stream, alternating accumulators (the per-half form waits for
+                // an LDS round trip in front of each of its KD dependent MFMAs: ~600 clocks for the six of d_k = 48)
+                f32x16 st0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st0[r] = st1[r] = 0.f;
+                mfma_stream<2 * KD>(
+                    [&](int i) { return lds_read_16B(smem, k_read_off[i >> 1] + stage + (i & 1) * 32 * C::KROW); },
+                    [&](int i, const u32x4 &a) {
+                        if (i & 1) { st1 = E::mfma(a, qf[i >> 1], st1); asm volatile("" : "+v"(st1)); }
+                        else { st0 = E::mfma(a, qf[i >> 1], st0); asm volatile("" : "+v"(st0)); }
+                    });
                 exponentiate(st0);
                 pack(st0, pf0);
             }
-            f32x16 st1 = scores(stage, 1);
             if (dma) issue(l2, kb2, slot2, 0x03u);
             // 8 MFMAs of half 0, keys 0..15, each followed by 2 fma + 2 exp of half 1; the C operand of MFMA n+1 is
             // requested before MFMA n issues, so the LDS latency hides behind a full MFMA
