@@ -155,22 +155,27 @@ __global__ __launch_bounds__(512) void sense_mix_dc_kernel(const MixBwdParams p)
             d_voff_p[j] = (uint32_t)(min(d_row[j], last_row) * p.do_rs + col) * 2u;
         }
 
-        auto issue = [&](int l, int qb, int slot, uint32_t pieces) {
+        // DMA pieces of the tile two steps ahead, (l2, qb2); its base pointers are carried and advanced on the scalar unit
+        // once per step (advance2), as in sense_mix_dma.hip
+        int l2 = 0, qb2 = qb_begin;
+        const int64_t q_tile_step = (int64_t)C::BQ * p.qk_rs, d_tile_step = (int64_t)C::BQ * p.do_rs;
+        const uint16_t *qs2 = qg + (int64_t)qb_begin * q_tile_step;   // first tile of sense l2
+        const uint16_t *qt2 = qs2;
+        const uint16_t *dt2 = dg + (int64_t)qb_begin * d_tile_step;
+        auto issue = [&](int, int, int slot, uint32_t pieces) {
             const uint32_t stage_off = lds0 + slot * C::STAGE;
-            const uint16_t *qt_ = qg + (int64_t)l * p.qk_ss + (int64_t)qb * C::BQ * p.qk_rs;
-            const uint16_t *dt_ = dg + (int64_t)qb * C::BQ * p.do_rs;
-            const bool partial = qb == qb_partial;
+            const bool partial = qb2 == qb_partial;
 #pragma unroll
             for (int j = 0; j < C::Q_DMA; ++j)
                 if ((pieces >> j) & 1u)
-                    dma16_s(qt_, partial ? q_voff_p[j] : q_voff[j], stage_off + (wave * C::Q_DMA + j) * 1024);
+                    dma16_s(qt2, partial ? q_voff_p[j] : q_voff[j], stage_off + (wave * C::Q_DMA + j) * 1024);
 #pragma unroll
             for (int j = 0; j < C::D_DMA; ++j)
                 if ((pieces >> (C::Q_DMA + j)) & 1u)
-                    dma16_s(dt_, partial ? d_voff_p[j] : d_voff[j], stage_off + C::QTILE + (wave * C::D_DMA + j) * 1024);
+                    dma16_s(dt2, partial ? d_voff_p[j] : d_voff[j], stage_off + C::QTILE + (wave * C::D_DMA + j) * 1024);
             if ((pieces >> (C::Q_DMA + C::D_DMA)) & 1u) {
-                // lse of the tile's 64 queries for sense l: lane i fetches lse[q0 + i] into the wave's own 256-B slot
-                const float *src = p.lse + ((int64_t)batch * p.nsenses + l) * p.lse_stride + min(qb * C::BQ + lane, S - 1);
+                // lse of the tile's 64 queries for sense l2: lane i fetches lse[q0 + i] into the wave's own 256-B slot
+                const float *src = p.lse + ((int64_t)batch * p.nsenses + l2) * p.lse_stride + min(qb2 * C::BQ + lane, S - 1);
                 dma4(src, stage_off + C::QTILE + C::DTILE + wave * 256);
             }
         };
@@ -227,30 +232,47 @@ __global__ __launch_bounds__(512) void sense_mix_dc_kernel(const MixBwdParams p)
             const u32x2 hi = lds_read_tr16_8B(smem, d_read_off[n & 3] + (n >> 2) * 256 + rows + 8 * C::DROW);
             return u32x4{lo[0], lo[1], hi[0], hi[1]};
         };
-        // dC^T += dout^T P for 16 queries (ks) of half kk
-        auto pv = [&](int stage, int kk, int ks, const u32x4 &pfk) {
-            const int rows = stage + C::QTILE + (kk * 32 + ks * 16) * C::DROW;
-#pragma unroll
-            for (int n = 0; n < C::NB; ++n)
-                if (FULL || n < nb_live) acc[n] = E::mfma(d_operand(rows, n), pfk, acc[n]);
+        // dC^T += dout^T P over N consecutive 16-query steps (pk[0..N-1]) from query row `row0` of the tile at `stage`, as
+        // one operand stream (mfma_stream, bp_common.h: the dout^T operand of MFMA i + 2 requested before MFMA i)
+        auto pv_stream = [&](int stage, int row0, const auto &pk, auto &&mid) {
+            constexpr int N = sizeof(pk) / sizeof(pk[0]) * C::NB;
+            const int base = stage + C::QTILE + row0 * C::DROW;
+            mfma_stream<N>([&](int i) { return d_operand(base + (i >> 3) * 16 * C::DROW, i & 7); },
+                           [&](int i, const u32x4 &a) {
+                               if (FULL || (i & 7) < nb_live) acc[i & 7] = E::mfma(a, pk[i >> 3], acc[i & 7]);
+                               asm volatile("" : "+v"(acc[i & 7]));
+                               mid(i);
+                           });
         };
 
-        // ---- steady-state step: every query of the tile exists and sees every key of the workgroup; softmax of
-        // half 1 pinned between the MFMAs of half 0 (see sense_mix_dma.hip for why the pins are needed)
-        auto clean_step = [&](int stage, int l2, int qb2, int slot2) {
-            u32x4 pf0[2], pf1[2];
+        // ---- steady-state step (every query of the tile exists and sees every key of the workgroup), cut as in
+        // sense_mix_dma.hip into a vector-heavy half X (S of both query halves as one operand stream, softmax of half 0,
+        // the first 8 MFMAs of half 0 with the exponentials of half 1 between them, pack) and a matrix-only half Y (the
+        // other 24 MFMAs); the two waves of a SIMD (w, w + 4) run them in anti-phase, X at raised priority.
+        u32x4 pfc[3];   // P of half 0 queries 16..31, of half 1 queries 0..15 and 16..31
+        auto clean_x = [&](int stage, int slot2, bool dma) {
+            __builtin_amdgcn_s_setprio(3);
+            u32x4 pf0[2];
+            f32x16 st1;
             {
-                f32x16 st0 = scores(stage, 0);
+                f32x16 st0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st0[r] = st1[r] = 0.f;
+                mfma_stream<2 * KD>(
+                    [&](int i) { return lds_read_16B(smem, q_read_off[i >> 1] + stage + (i & 1) * 32 * C::QROW); },
+                    [&](int i, const u32x4 &a) {
+                        if (i & 1) { st1 = E::mfma(a, kf[i >> 1], st1); asm volatile("" : "+v"(st1)); }
+                        else { st0 = E::mfma(a, kf[i >> 1], st0); asm volatile("" : "+v"(st0)); }
+                    });
                 float lq[16];
                 row_lse(stage, 0, lq);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) st0[r] = fast_exp2(fmaf(st0[r], c2, -lq[r]));
                 pack(st0, pf0);
             }
-            f32x16 st1 = scores(stage, 1);
             float lq1[16];
             row_lse(stage, 1, lq1);
-            issue(l2, qb2, slot2, 0x01u);
+            if (dma) issue(0, 0, slot2, 0x03u);
             {
                 const int rows = stage + C::QTILE;
                 u32x4 a = d_operand(rows, 0);
@@ -271,27 +293,20 @@ __global__ __launch_bounds__(512) void sense_mix_dc_kernel(const MixBwdParams p)
                     a = a_next;
                 }
             }
-            issue(l2, qb2, slot2, 0x02u);
-            {
-                const int rows = stage + C::QTILE + 16 * C::DROW;
-                u32x4 a = d_operand(rows, 0);
-#pragma unroll
-                for (int n = 0; n < C::NB; ++n) {
-                    u32x4 a_next = a;
-                    if (n + 1 < C::NB) a_next = d_operand(rows, n + 1);
-                    asm volatile("" : "+v"(a));
-                    acc[n] = E::mfma(a, pf0[1], acc[n]);
-                    asm volatile("" : "+v"(acc[n]));
-                    uint32_t w = E::pack2(st1[2 * n], st1[2 * n + 1]);
-                    asm volatile("" : "+v"(w));
-                    pf1[n >> 2][n & 3] = w;
-                    a = a_next;
-                }
-            }
-            issue(l2, qb2, slot2, 0x0cu);
-            pv(stage, 1, 0, pf1[0]);
-            issue(l2, qb2, slot2, kAllPieces & ~0x0fu);
-            pv(stage, 1, 1, pf1[1]);
+            if (dma) issue(0, 0, slot2, kAllPieces & ~0x03u);
+            pfc[0] = pf0[1];
+            u32x4 pf1[2];
+            pack(st1, pf1);
+            pfc[1] = pf1[0];
+            pfc[2] = pf1[1];
+            asm volatile("" : "+v"(pfc[0]), "+v"(pfc[1]), "+v"(pfc[2]));   // the packs belong to X, not behind the barrier
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto clean_y = [&](int stage, int slot2, bool dma) {
+            if (dma) issue(0, 0, slot2, 0x03u);
+            pv_stream(stage, 16, pfc, [&](int i) {
+                if (i == 11 && dma) issue(0, 0, slot2, kAllPieces & ~0x03u);
+            });
         };
 
         // ---- a step in the diagonal region or on the partial last tile: per-half liveness, masking
@@ -325,19 +340,25 @@ __global__ __launch_bounds__(512) void sense_mix_dc_kernel(const MixBwdParams p)
                                 pf[ks][i] &= keep;
                             }
                     }
-                    pv(stage, kk, 0, pf[0]);
+                    pv_stream(stage, kk * 32, pf, [](int) {});
                 }
-                issue(l2, qb2, slot2, kk == 0 ? 0x02u : (kAllPieces & ~0x0fu));
-                if (live) pv(stage, kk, 1, pf[1]);
-                if (kk == 0) issue(l2, qb2, slot2, 0x0cu);
+                issue(l2, qb2, slot2, kk == 0 ? 0x0eu : (kAllPieces & ~0x0fu));
             }
         };
 
         // ---- pipeline: two tiles in flight (steps past the end re-fetch the last tile, see sense_mix_dma.hip) -----
-        int l2 = 0, qb2 = qb_begin;
         auto advance2 = [&]() {
-            if (qb2 + 1 < nqb) { ++qb2; }
-            else if (l2 + 1 < p.nsenses) { ++l2; qb2 = qb_begin; }
+            if (qb2 + 1 < nqb) {
+                ++qb2;
+                qt2 += q_tile_step;
+                dt2 += d_tile_step;
+            } else if (l2 + 1 < p.nsenses) {
+                ++l2;
+                qb2 = qb_begin;
+                qs2 += p.qk_ss;
+                qt2 = qs2;
+                dt2 = dg + (int64_t)qb_begin * d_tile_step;   // dout does not depend on the sense
+            }
         };
         issue(0, qb_begin, 0, kAllPieces);
         advance2();
@@ -365,10 +386,18 @@ __global__ __launch_bounds__(512) void sense_mix_dc_kernel(const MixBwdParams p)
                 edge_step(slot * C::STAGE, qb, l2, qb2, slot >= 1 ? slot - 1 : 2);
                 step_end();
             }
-            for (int qb = qb_clean; qb < qb_full_end; ++qb) {
-                step_begin();
-                clean_step(slot * C::STAGE, l2, qb2, slot >= 1 ? slot - 1 : 2);
-                step_end();
+            // clean steps, two barriers each; waves 4-7 one barrier late (see sense_mix_dma.hip for the ring argument)
+            if (qb_clean < qb_full_end) {
+                const bool late = wave >= C::NWAVE / 2;
+                if (late) step_begin();
+                for (int qb = qb_clean; qb < qb_full_end; ++qb) {
+                    step_begin();
+                    clean_x(slot * C::STAGE, slot >= 1 ? slot - 1 : 2, late);
+                    step_begin();
+                    clean_y(slot * C::STAGE, slot >= 1 ? slot - 1 : 2, !late);
+                    step_end();
+                }
+                if (!late) __builtin_amdgcn_s_barrier();
             }
             for (int qb = max(qb_clean, qb_full_end); qb < nqb; ++qb) {
                 step_begin();
