@@ -570,6 +570,63 @@ __global__ __launch_bounds__(256) void sense_dq_kernel(const SenseGradParams p) 
     // dP^T tile: 256-B rows = 4 chunks of 64 B (one per wave's 32 queries), chunk index swizzled with row & 3
     const int p_read_off = v_lds_off<4>(t_row_lane, wave * 4 + t_ch_lane) + (lane & 1) * 8;
 
+    // Row reference r[t] ~ D[t], estimated from the first 32 keys as sum P dP / sum P (key 0 is visible to every query,
+    // so the denominator is positive): the softmax backward is invariant under dP -> dP - r[t], and a component of
+    // dout . C that is common to all keys of a row -- the bias of the sense network's last layer is one -- would
+    // otherwise survive into the 16-bit products P dP and cancel only in A1 - D A2
+    // (tests: ..._with_a_common_offset_in_dout_c).  With g = P (dP - r):
+    //     D = sum g + r sum P,      dq = scale (sum g k - (sum g + r (sum P - 1)) sum P k).
+    float rref = 0.f, psum = 0.f;
+    // one 32-key sub-block; REF: only sum P dP and sum P over it (into dsum / psum), no products
+    auto sub_block = [&](const char *k_r, const char *k_t, const char *dp_t, int kb, int kk, auto REF) {
+        constexpr bool kRef = decltype(REF)::value;
+        const int kbase = kb * C::BK + kk * 32;
+        f32x16 st_;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st_[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KD; ++s) {
+            const u32x4 a = lds_read_16B(k_r, r_read_off[s] + kk * 32 * C::KROW);
+            st_ = E::mfma(a, qf[s], st_);
+        }
+        u32x4 pf[2], gf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            // dP^T of keys {0..3, 8..11} + 4 hh + 16 ks for my query: same order as the S^T registers
+            const int rows = (kk * 32 + ks * 16) * 256;
+            const u32x2 lo = lds_read_tr16_8B(dp_t, p_read_off + rows);
+            const u32x2 hi = lds_read_tr16_8B(dp_t, p_read_off + rows + 8 * 256);
+            const uint32_t dw[4] = {lo[0], lo[1], hi[0], hi[1]};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = ks * 8 + 2 * i;
+                const int key = kbase + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                float p0 = fast_exp2(fmaf(st_[r], c2, -lse2));
+                float p1 = fast_exp2(fmaf(st_[r + 1], c2, -lse2));
+                if (key > my_q || key >= S) p0 = 0.f;
+                if (key + 1 > my_q || key + 1 >= S) p1 = 0.f;
+                const uint32_t d = dw[i];   // by-value copy (bp_common.h)
+                const float g0 = p0 * (E::lo_f32(d) - rref), g1 = p1 * (E::hi_f32(d) - rref);
+                dsum += g0 + g1;
+                psum += p0 + p1;
+                pf[ks][i] = E::pack2(p0, p1);
+                gf[ks][i] = E::pack2(g0, g1);
+            }
+        }
+        if (kRef) return;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int rows = (kk * 32 + ks * 16) * C::TROW;
+#pragma unroll
+            for (int n = 0; n < NVK; ++n) {
+                const u32x2 lo = lds_read_tr16_8B(k_t, t_read_off[n] + rows);
+                const u32x2 hi = lds_read_tr16_8B(k_t, t_read_off[n] + rows + 8 * C::TROW);
+                const u32x4 a = {lo[0], lo[1], hi[0], hi[1]};
+                a1[n] = E::mfma(a, gf[ks], a1[n]);
+                a2[n] = E::mfma(a, pf[ks], a2[n]);
+            }
+        }
+    };
     if (nkb > 0) issue(0);
     for (int kb = 0; kb < nkb; ++kb) {
         wait_vmcnt<0>();
@@ -578,60 +635,28 @@ __global__ __launch_bounds__(256) void sense_dq_kernel(const SenseGradParams p) 
         if (!wave_has_rows || kb * C::BK > q0 + 31) continue;
         const char *st = smem + (kb & 1) * STAGE;
         const char *k_r = st, *k_t = st + RTILE, *dp_t = st + RTILE + TTILE;
+        if (kb == 0) {
+            sub_block(k_r, k_t, dp_t, 0, 0, std::true_type{});
+            const float num = xhalf_sum(dsum), den = xhalf_sum(psum);
+            rref = den > 0.f ? num / den : 0.f;
+            // the slab holds 16-bit values: a reference of the same precision keeps dP - r exact for dP near r
+            rref = E::lo_f32(E::pack2(rref, 0.f));
+            dsum = 0.f;
+            psum = 0.f;
+        }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int kbase = kb * C::BK + kk * 32;
             if (kbase >= S || kbase > q0 + 31) continue;
-            f32x16 st_;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st_[r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < KD; ++s) {
-                const u32x4 a = lds_read_16B(k_r, r_read_off[s] + kk * 32 * C::KROW);
-                st_ = E::mfma(a, qf[s], st_);
-            }
-            u32x4 pf[2], gf[2];
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                // dP^T of keys {0..3, 8..11} + 4 hh + 16 ks for my query: same order as the S^T registers
-                const int rows = (kk * 32 + ks * 16) * 256;
-                const u32x2 lo = lds_read_tr16_8B(dp_t, p_read_off + rows);
-                const u32x2 hi = lds_read_tr16_8B(dp_t, p_read_off + rows + 8 * 256);
-                const uint32_t dw[4] = {lo[0], lo[1], hi[0], hi[1]};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = ks * 8 + 2 * i;
-                    const int key = kbase + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    float p0 = fast_exp2(fmaf(st_[r], c2, -lse2));
-                    float p1 = fast_exp2(fmaf(st_[r + 1], c2, -lse2));
-                    if (key > my_q || key >= S) p0 = 0.f;
-                    if (key + 1 > my_q || key + 1 >= S) p1 = 0.f;
-                    const uint32_t d = dw[i];   // by-value copy (bp_common.h)
-                    const float g0 = p0 * E::lo_f32(d), g1 = p1 * E::hi_f32(d);
-                    dsum += g0 + g1;
-                    pf[ks][i] = E::pack2(p0, p1);
-                    gf[ks][i] = E::pack2(g0, g1);
-                }
-            }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int rows = (kk * 32 + ks * 16) * C::TROW;
-#pragma unroll
-                for (int n = 0; n < NVK; ++n) {
-                    const u32x2 lo = lds_read_tr16_8B(k_t, t_read_off[n] + rows);
-                    const u32x2 hi = lds_read_tr16_8B(k_t, t_read_off[n] + rows + 8 * C::TROW);
-                    const u32x4 a = {lo[0], lo[1], hi[0], hi[1]};
-                    a1[n] = E::mfma(a, gf[ks], a1[n]);
-                    a2[n] = E::mfma(a, pf[ks], a2[n]);
-                }
-            }
+            sub_block(k_r, k_t, dp_t, kb, kk, std::false_type{});
         }
     }
 
     if (!wave_has_rows) return;
-    const float d_tot = xhalf_sum(dsum);
+    const float g_tot = xhalf_sum(dsum), p_tot = xhalf_sum(psum);
+    const float d_tot = fmaf(rref, p_tot - 1.f, g_tot);    // D - r: what multiplies sum P k
     if (my_q < S) {
-        if (hh == 0) p.dsum[((int64_t)batch * p.nsenses + l) * p.lse_stride + my_q] = d_tot;
+        if (hh == 0) p.dsum[((int64_t)batch * p.nsenses + l) * p.lse_stride + my_q] = fmaf(rref, p_tot, g_tot);   // D itself
         uint16_t *dqg = reinterpret_cast<uint16_t *>(p.dq) + batch * p.dq_bs + (int64_t)my_q * p.dq_rs + (int64_t)l * p.dq_ss;
 #pragma unroll
         for (int n = 0; n < NVK; ++n)
