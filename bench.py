@@ -27,6 +27,9 @@ for _p in (ROOT, PKG):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+# the host driver of this pool only supports dmabuf IPC: without it RCCL's cross-process buffer sharing fails with
+# `hipIpcGetMemHandle: invalid argument` at world size > 1 (the image exports it; a bare launcher may not)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 import torch  # noqa: E402
 
 # MI355X peaks from /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)

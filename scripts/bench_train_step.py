@@ -18,6 +18,9 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, 'backpacks-flash-attn_amd')):
     sys.path.insert(0, p)
+# the host driver of this pool only supports dmabuf IPC: without it RCCL's cross-process buffer sharing fails with
+# `hipIpcGetMemHandle: invalid argument` at world size > 1 (the image exports it; a bare launcher may not)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 import torch  # noqa: E402
 
 
