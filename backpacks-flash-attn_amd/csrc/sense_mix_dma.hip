@@ -12,19 +12,21 @@
 //     ds_read_b64_tr_b16 (C) conflict-free are applied to the per-lane SOURCE address.  Every lane of every
 //     DMA piece moves VALID data (pad slots receive a duplicate of column 0): K pad columns meet zero Q columns,
 //     C pad columns feed output columns that are never stored, so nothing is predicated and nothing is zeroed.
-//   * the two waves of a SIMD leave the tile barrier together, so without care both sit in their softmax
-//     (VALU, matrix pipe idle) and then both in their 16 MFMAs (VALU idle) at the same time -- a lone workgroup
-//     measured 49 % MFMA utilisation that way (r02_a).  The steady-state step therefore software-pipelines
-//     inside the wave: both S^T halves first, softmax of half 0, then the 16 MFMAs of half 0 are issued WITH the
-//     softmax of half 1 between them (independent registers, one basic block: no branch, no predicated DMA).
-//     Steps that touch the diagonal (some waves dead or masking) keep the simple per-half form.
+//   * the two waves of a SIMD (w and w + 4) leave a tile barrier together, so in a one-phase step both sit in their
+//     softmax (VALU, matrix pipe idle) and then both in their MFMAs (VALU idle): the per-phase clock account of round 3
+//     (scripts/probes/mix_timeline) found the sum of the phases' lower bounds equal to the measured step, 4085 clocks
+//     against 2432 of matrix-pipe time.  A clean step is therefore two halves under two barriers -- X: S^T, softmax of
+//     key half 0, 8 MFMAs with the exponentials of half 1 between them; Y: the other 24 MFMAs -- and waves 4-7 run the
+//     clean loop one barrier late, so X of one wave always meets Y of its partner.  Every MFMA operand that comes from LDS
+//     is requested two MFMAs ahead (mfma_stream, bp_common.h).  Steps that touch the diagonal (some waves dead or
+//     masking) keep the simple per-half form.
 //   * PERSISTENT launch: one workgroup per CU pulls (group, query tile) jobs from 8 per-XCD queues, heaviest
 //     query tiles first, stealing from the other queues when its own is empty.  The hardware dispatcher places
 //     workgroups in order and round-robin: with one workgroup per CU and jobs of 4,3,2,1 units that gave rounds of
 //     4+3+2 = 9 units per CU against 7.5 ideal (dispatch_order probe); a static snake assignment lost
 //     to run-time variance (r01).  A group's tiles still prefer one XCD, i.e. one L2 holds its C tiles.
 //     Queue state: a 64-byte record of device memory, the caller's (`queue_ws`) or one of a small ring owned by the
-//     library, zeroed by a memset node in front of every launch, see arm_mix_queues.
+//     library, zeroed by a one-wave kernel in front of every launch, see arm_mix_queues.
 // Rows past the sequence are fetched from a clamped (valid) row: their probabilities are exactly 0 by the
 // causal mask and 0 * finite = 0.
 #include <atomic>
