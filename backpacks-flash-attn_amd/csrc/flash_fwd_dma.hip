@@ -23,6 +23,12 @@
 //   * in-kernel dropout (training; reference fmha_fprop_kernel_1xN.h:494-506): counter-based bits per
 //     (batch*head, query, key), see bp_philox.h; dropped probabilities are zeroed AFTER the row sum, the
 //     output is scaled by 1 / (1 - p) once in the epilogue.
+// S^T of both key halves as one operand stream (mfma_stream, bp_common.h) instead of two dependent per-half chains:
+// +0.5 ... 1.7 % (r03_ao), 125 registers = still four waves per SIMD once the partial-tile DMA offsets left the
+// register file (see issue())
+#ifndef BP_FWD_STREAM
+#define BP_FWD_STREAM 1
+#endif
 #include "bp_common.h"
 #include "bp_dma.h"
 #include "bp_kernels.h"
@@ -35,6 +41,19 @@
 #endif
 
 namespace bp {
+
+// Development builds only (-DBP_FWD_PROFILE, scripts/probes/flash_fwd_phases): every wave adds up s_memtime deltas per
+// phase of a pass; never in the shipped library.
+#ifdef BP_FWD_PROFILE
+// [workgroup][wave][0 wait+barrier, 1 DMA issue, 2 S^T, 3 softmax, 4 PV, 5 exact tiles (whole), 6 #fast tiles, 7 pass clocks,
+//  8 prologue (pass start -> first ring step), 9 epilogue, 10 #passes]
+__device__ unsigned long long g_fwd_prof[8192][4][12];
+#define FWD_TICK(var) const unsigned long long var = __builtin_readcyclecounter()
+#define FWD_ADD(k, expr) prof[k] += (expr)
+#else
+#define FWD_TICK(var) do { } while (0)
+#define FWD_ADD(k, expr) do { } while (0)
+#endif
 
 template <int KD, int NV, bool HAS_V>
 struct FlashDmaCfg {
@@ -84,6 +103,10 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
         q_off = batch * p.q_bs; o_off = batch * p.o_bs; k_off = batch * p.k_bs; v_off = batch * p.v_bs;
     }
     if (qt * C::BM >= seq_q) return;
+#ifdef BP_FWD_PROFILE
+    unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    FWD_TICK(pass_t0);
 
     const uint16_t *qg = reinterpret_cast<const uint16_t *>(p.q) + q_off + (int64_t)head * p.q_hs;
     const uint16_t *kg = reinterpret_cast<const uint16_t *>(p.k) + k_off + (int64_t)head * p.k_hs;
@@ -155,36 +178,47 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
         }
     }
     // Scalar tile base + constant per-lane byte offset -> no VALU at all.  The only partial tile a sweep can meet is
-    // the sequence's last one; its rows are clamped to the final valid key (those keys are masked later) through a
-    // second, precomputed offset set and a uniform select.
+    // the sequence's last one; its rows are clamped to the final valid key (those keys are masked later): the clamped
+    // offsets are recomputed from the lane's row in that one (cold) step instead of living in registers all along.
     const int kb_partial = (seq_k % C::BN) != 0 ? seq_k / C::BN : -1;
     const int last_row = seq_k - 1 - (seq_k / C::BN) * C::BN;
-    uint32_t k_voff_p[C::K_DMA], v_voff_p[HAS_V ? C::V_DMA : 1];
-#pragma unroll
-    for (int j = 0; j < C::K_DMA; ++j) k_voff_p[j] = (uint32_t)(min(k_row[j], last_row) * p.k_rs + k_col[j]) * 2u;
-    if (HAS_V) {
-#pragma unroll
-        for (int j = 0; j < C::V_DMA; ++j) v_voff_p[j] = (uint32_t)(min(v_row[j], last_row) * p.v_rs + v_col[j]) * 2u;
-    }
     const int64_t k_tile_stride = (int64_t)C::BN * p.k_rs, v_tile_stride = (int64_t)C::BN * p.v_rs;
     const uint16_t *kt = kg, *vt = vg;   // tile kb of the NEXT issue (tiles are issued in order 0, 1, 2, ...)
     auto issue = [&](int kb) {
         // (readfirstlane: inside the per-lane predicate of the !FULLD case hipcc may hold the uniform address in a VGPR)
         const uint32_t stage = __builtin_amdgcn_readfirstlane(lds0 + (kb & 1) * C::STAGE);
-        const bool partial = kb == kb_partial;
+        if (__builtin_expect(kb == kb_partial, 0)) {
 #pragma unroll
-        for (int j = 0; j < C::K_DMA; ++j)
-            if (FULLD || k_col[j] < p.d)
-                dma16_s(kt, partial ? k_voff_p[j] : k_voff[j],
-                        __builtin_amdgcn_readfirstlane(stage + (wave * C::K_DMA + j) * 1024));
-        if (HAS_V) {
+            for (int j = 0; j < C::K_DMA; ++j) {
+                const int row = (wave * C::K_DMA + j) * C::K_ROWS_PER_DMA + lane / C::KSLOTS;
+                const uint32_t back = (uint32_t)(max(row - last_row, 0) * p.k_rs) * 2u;
+                if (FULLD || k_col[j] < p.d)
+                    dma16_s(kt, k_voff[j] - back, __builtin_amdgcn_readfirstlane(stage + (wave * C::K_DMA + j) * 1024));
+            }
+            if (HAS_V) {
 #pragma unroll
-            for (int j = 0; j < C::V_DMA; ++j)
-                if (FULLD || v_col[j] < p.d)
-                    dma16_s(vt, partial ? v_voff_p[j] : v_voff[j],
-                            __builtin_amdgcn_readfirstlane(stage + C::KTILE + (wave * C::V_DMA + j) * 1024));
-            vt += v_tile_stride;
+                for (int j = 0; j < C::V_DMA; ++j) {
+                    const int row = ((wave * C::V_DMA + j) * 64 + lane) / C::VCH;
+                    const uint32_t back = (uint32_t)(max(row - last_row, 0) * p.v_rs) * 2u;
+                    if (FULLD || v_col[j] < p.d)
+                        dma16_s(vt, v_voff[j] - back,
+                                __builtin_amdgcn_readfirstlane(stage + C::KTILE + (wave * C::V_DMA + j) * 1024));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < C::K_DMA; ++j)
+                if (FULLD || k_col[j] < p.d)
+                    dma16_s(kt, k_voff[j], __builtin_amdgcn_readfirstlane(stage + (wave * C::K_DMA + j) * 1024));
+            if (HAS_V) {
+#pragma unroll
+                for (int j = 0; j < C::V_DMA; ++j)
+                    if (FULLD || v_col[j] < p.d)
+                        dma16_s(vt, v_voff[j],
+                                __builtin_amdgcn_readfirstlane(stage + C::KTILE + (wave * C::V_DMA + j) * 1024));
+            }
         }
+        if (HAS_V) vt += v_tile_stride;
         kt += k_tile_stride;
     };
 
@@ -354,19 +388,52 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
     auto tile = [&](int kb, const char *kbuf, const char *vbuf, bool exact) {
         f32x16 st[2];
         float rs;
+        const bool fast_entry = !exact;
+        FWD_TICK(t0);
+#ifdef BP_FWD_PROFILE
+        unsigned long long t_s = t0, t_e = t0;
+#endif
         for (;;) {
+#if BP_FWD_STREAM
+            {   // both halves as one operand stream, alternating accumulators; operand i + 2 requested before MFMA i
+                f32x16 zero;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+                mfma_stream<2 * KD>(
+                    [&](int i) { return lds_read_16B(kbuf, k_read_off[i >> 1] + (i & 1) * 32 * C::KROW); },
+                    [&](int i, const u32x4 &a) { st[i & 1] = E::mfma(a, qf[i >> 1], i < 2 ? zero : st[i & 1]); });
+            }
+#else
             st[0] = scores(kbuf, 0);
             st[1] = scores(kbuf, 1);
+#endif
+#ifdef BP_FWD_PROFILE
+            asm volatile("" : "+v"(st[0]), "+v"(st[1]));
+            t_s = __builtin_readcyclecounter();
+#endif
             if (__builtin_expect(exact, 0)) online_max_step(kb, st);
             rs = PACKED_SUM ? exponentiate_packed(st) : exponentiate(st);
             if (__builtin_expect(exact || __all(rs <= kLimit), 1)) break;   // inf and NaN fail the test too
             exact = true;
         }
+#ifdef BP_FWD_PROFILE
+        if (PACKED_SUM) asm volatile("" : "+v"(pf[0][0]), "+v"(pf[0][1]), "+v"(pf[1][0]), "+v"(pf[1][1]), "+v"(rs));
+        t_e = __builtin_readcyclecounter();
+#endif
         l_run += rs;
         // second 32-key half entirely above my rows (diagonal tile): all its p are 0
         const bool skip_hi = p.causal && (kb * C::BN + 32 > q0 + 31);
         if (PACKED_SUM) accumulate_packed(vbuf, skip_hi);
         else accumulate(kb, vbuf, st, skip_hi);
+#ifdef BP_FWD_PROFILE
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[NV - 1]));
+        const unsigned long long t_p = __builtin_readcyclecounter();
+        if (fast_entry && !exact) {
+            prof[2] += t_s - t0; prof[3] += t_e - t_s; prof[4] += t_p - t_e; prof[6] += 1;
+        } else {
+            prof[5] += t_p - t0;
+        }
+#endif
     };
 
     if (nkb > 0) issue(0);
@@ -374,9 +441,17 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
     // the LDS addresses of all operand reads fold into instruction offsets.
     auto ring_step = [&](int kb, auto SLOT) {
         constexpr int kSlot = decltype(SLOT)::value;
+        FWD_TICK(r0);
+#ifdef BP_FWD_PROFILE
+        if (kb == 0) prof[8] += r0 - pass_t0;
+#endif
         wait_vmcnt<0>();                    // my share of tile kb has landed ...
         __builtin_amdgcn_s_barrier();       // ... so has everybody's; all waves are done reading the other slot
+        FWD_TICK(r1);
+        FWD_ADD(0, r1 - r0);
         if (kb + 1 < nkb) issue(kb + 1);
+        FWD_TICK(r2);
+        FWD_ADD(1, r2 - r1);
         if (kb < my_nkb) {
             const char *kbuf = smem + kSlot * C::STAGE;
             const char *vbuf = kbuf + C::KTILE;
@@ -388,7 +463,17 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
         if (kb + 1 < nkb) ring_step(kb + 1, std::integral_constant<int, 1>{});
     }
 
+    FWD_TICK(ep0);
+#ifdef BP_FWD_PROFILE
+    auto flush = [&](unsigned long long t_end) {
+        prof[9] += t_end - ep0; prof[7] += t_end - pass_t0; prof[10] += 1;
+        if (lane == 0 && blockIdx.x < 8192)
+            for (int k = 0; k < 12; ++k) atomicAdd(&g_fwd_prof[blockIdx.x][wave][k], prof[k]);
+    };
+    if (!wave_has_rows) { flush(__builtin_readcyclecounter()); return; }
+#else
     if (!wave_has_rows) return;
+#endif
     const float l_tot = xhalf_sum(l_run);
     float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
     if (DROP) inv *= p.drop_scale;
@@ -412,6 +497,9 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
                 }
         }
     }
+#ifdef BP_FWD_PROFILE
+    flush(__builtin_readcyclecounter());
+#endif
 }
 
 // Work order.  The dispatcher hands workgroups to the CUs of an XCD strictly round-robin and IN ORDER: block
@@ -479,5 +567,16 @@ static hipError_t launch_et(const FlashParams &p, hipStream_t stream) {
 hipError_t launch_flash_fwd_dma(const FlashParams &p, int dtype, hipStream_t stream) {
     return dtype == 1 ? launch_et<BF16>(p, stream) : launch_et<F16>(p, stream);
 }
+
+#ifdef BP_FWD_PROFILE
+extern "C" int bp_dev_fwd_prof(unsigned long long *host, int clear) {
+    if (clear) {
+        void *ptr = nullptr;
+        if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_fwd_prof)) != hipSuccess) return -1;
+        return hipMemset(ptr, 0, sizeof(g_fwd_prof)) == hipSuccess ? 0 : -1;
+    }
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fwd_prof), sizeof(g_fwd_prof)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // namespace bp
