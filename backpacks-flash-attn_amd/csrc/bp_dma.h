@@ -55,7 +55,9 @@ BP_DEV void dma4(const void *g, uint32_t lds_addr) {
 // Same, "saddr" form: wave-uniform 64-bit base in SGPRs + per-lane 32-bit BYTE offset.  The per-tile
 // address update then happens on the scalar unit (base += tile stride) and costs no VALU.
 // M0 is named as clobbered instead of being saved and restored around the instruction (two scalar moves per piece
-// less; the compiler reloads M0 itself where it needs it).
+// less).  hipcc notes that a reserved register on a clobber list "may not be preserved": that is the intent -- M0 is never
+// allocated to a value, the compiler writes it immediately in front of each instruction of its own that reads it
+// (none in these kernels: DS instructions do not use M0 on gfx9+), so nothing can be live in it across the statement.
 BP_DEV void dma16_s(const uint16_t *uniform_base, uint32_t lane_byte_off, uint32_t lds_addr) {
     asm volatile(
         "s_mov_b32 m0, %2\n\t"
