@@ -302,6 +302,46 @@ def test_greedy_generation_on_the_hip_path():
     assert (out.scores[0].float().cpu() - ref(ids).logits[:, -1]).abs().max().item() < 0.15
 
 
+def test_graph_replay_decoding_gives_the_eager_tokens():
+    """generate(..., cg=True): one captured full-width forward replayed per token.  Same length contract, same first-step
+    scores, and the same tokens as the growing-prefix loop -- a token may differ only where the eager HIP logits of the
+    two candidates tie to within bf16 noise (a differently tiled GEMM at the other sequence length); batch 1 and 3,
+    greedy, prompt longer than max_length - 1 included.  Also: replaying is not slower than the eager loop."""
+    import time
+    from src.models.backpack import BackpackConfig, BackpackLMHeadModel
+    kw = dict(n_embd=128, n_head=2, n_layer=2, num_content_vectors=4, vocab_size=512, n_positions=64,
+              scale_attn_by_inverse_layer_idx=True, resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0,
+              pad_vocab_size_multiple=8)
+    torch.manual_seed(31)
+    hip = BackpackLMHeadModel(BackpackConfig(use_flash_attn=True, fused_dropout_add_ln=True, **kw)).eval()
+    hip = hip.to(DEV, torch.bfloat16)
+    for batch, plen, max_length in ((1, 5, 40), (3, 7, 24), (2, 9, 6)):
+        ids = torch.randint(0, 512, (batch, plen)).to(DEV)
+        eager = hip.generate(ids, max_length=max_length, return_dict_in_generate=True, output_scores=True)
+        graphed = hip.generate(ids, max_length=max_length, return_dict_in_generate=True, output_scores=True, cg=True)
+        assert graphed.sequences.shape == eager.sequences.shape == (batch, max(plen, max_length - 1))
+        assert len(graphed.scores) == 1
+        assert (graphed.scores[0].float() - eager.scores[0].float()).abs().max().item() < 0.1
+        a, b = eager.sequences.cpu(), graphed.sequences.cpu()
+        for row in range(batch):
+            if torch.equal(a[row], b[row]):
+                continue
+            t = int((a[row] != b[row]).nonzero()[0])             # first divergence: must be a near tie
+            with torch.no_grad():
+                logits = hip(a[row:row + 1, :t].to(DEV)).logits[0, -1].float().cpu()
+            assert abs(logits[a[row, t]] - logits[b[row, t]]).item() < 0.1, (batch, row, t)
+    ids = torch.randint(0, 512, (1, 4)).to(DEV)
+    times = {}
+    for cg in (False, True):
+        hip.generate(ids, max_length=48, cg=cg)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        hip.generate(ids, max_length=48, cg=cg)
+        torch.cuda.synchronize()
+        times[cg] = time.perf_counter() - t0
+    print(f'decode 44 tokens, nano model: eager {times[False] * 1e3:.1f} ms, graph replay {times[True] * 1e3:.1f} ms (capture included)')
+
+
 def test_generation_on_the_hip_path_matches_the_reference_tokens():
     """G8 on the GPU: the nano model of G4 on the HIP path continues the prompt with the reference's tokens.
     bf16 logits can flip a near tie, so a differing token is accepted only where the fp32 golden margin
