@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('BP_HIP_LIB') or os.path.join(_HERE, 'libbackpack_hip.so')  # env: A/B builds only
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 
@@ -25,8 +25,10 @@ SIGNATURES = {
     'bp_abi_version': (_i32, []),
     'bp_flash_fwd': (_i32, [_ptr] * 7 + [_i32] * 5 + [_i64] * 9 + [_f32, _i32, _i32, _ptr]),
     'bp_flash_fwd_dropout': (_i32, [_ptr] * 7 + [_i32] * 5 + [_i64] * 9 + [_f32, _i32, _i32, _f32, _ptr, _ptr]),
-    'bp_flash_bwd': (_i32, [_ptr] * 12 + [_i32] * 5 + [_i64] * 17 + [_f32, _i32, _i32, _ptr]),
-    'bp_flash_bwd_dropout': (_i32, [_ptr] * 12 + [_i32] * 5 + [_i64] * 17 + [_f32, _i32, _i32, _f32, _ptr, _ptr]),
+    'bp_flash_bwd_ws_floats': (_i64, [_i32, _i32, _i64]),
+    'bp_flash_bwd': (_i32, [_ptr] * 7 + [_i64] + [_ptr] * 5 + [_i32] * 5 + [_i64] * 17 + [_f32, _i32, _i32, _ptr]),
+    'bp_flash_bwd_dropout': (_i32, [_ptr] * 7 + [_i64] + [_ptr] * 5 + [_i32] * 5 + [_i64] * 17
+                             + [_f32, _i32, _i32, _f32, _ptr, _ptr]),
     'bp_attn_probs': (_i32, [_ptr] * 4 + [_i32] * 5 + [_i64] * 10 + [_f32, _i32, _i32, _ptr]),
     'bp_attn_probs_dropout': (_i32, [_ptr] * 4 + [_i32] * 5 + [_i64] * 10 + [_f32, _i32, _i32, _f32, _ptr, _ptr]),
     'bp_sense_lse': (_i32, [_ptr] * 2 + [_i32] * 4 + [_i64] * 4 + [_f32, _i32, _ptr]),
@@ -236,11 +238,11 @@ def flash_bwd(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seql
         out = out.contiguous()
     # workspace for the row statistics -D_i = -sum_d dO_i[d] * O_i[d] and -L_i / scale (filled by the dQ kernel, read
     # by the dK/dV kernel)
-    dsum = torch.empty((batch, nheads, 2, lse_len), dtype=torch.float32, device=q.device)
+    dsum = torch.empty(int(lib().bp_flash_bwd_ws_floats(batch, nheads, lse_len)), dtype=torch.float32, device=q.device)
     with torch.cuda.device(q.device):
         code = lib().bp_flash_bwd_dropout(
             dout.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
-            softmax_lse.data_ptr(), dsum.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+            softmax_lse.data_ptr(), dsum.data_ptr(), dsum.numel(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
             cu_seqlens_q.data_ptr() if cu_seqlens_q is not None else None,
             cu_seqlens_k.data_ptr() if cu_seqlens_k is not None else None,
             batch, nheads, d, int(max_seqlen_q), int(max_seqlen_k),
@@ -278,7 +280,9 @@ def attn_probs(q, k, lse, softmax_scale, causal, dropout_p=0.0, rng_state=None):
 def _queue_ws(device):
     """The 64-byte ticket record of ONE persistent sense-mix launch (include/bp_hip.h: queue_ws).  A fresh tensor per
     call from torch's stream-ordered caching allocator: while a HIP graph is being captured it comes from the graph's
-    private pool, so the graph owns the record it replays and no eager launch can ever share it."""
+    private pool, so the graph owns the record it replays and no eager launch can ever share it.  The caller keeps the
+    tensor in a local until the launch call has returned: the block then goes back to the allocator of the stream the
+    launch was enqueued on (allocation and launch both use torch's CURRENT stream), whose reuse is stream-ordered."""
     return torch.empty(16, dtype=torch.int32, device=device)
 
 
@@ -371,6 +375,7 @@ def sense_mix(qk, content, softmax_scale=None, out=None, lse=None, key_weight=No
         kw = key_weight.to(torch.float32)
         if kw.stride(-1) != 1:
             kw = kw.contiguous()
+    queue_ws = _queue_ws(qk.device)   # alive until the launch call has returned (stream-ordered reuse afterwards)
     with torch.cuda.device(qk.device):
         code = lib().bp_sense_mix_weighted(
             qk.data_ptr(), content.data_ptr(), kw.data_ptr() if kw is not None else None, out.data_ptr(),
@@ -378,7 +383,8 @@ def sense_mix(qk, content, softmax_scale=None, out=None, lse=None, key_weight=No
             qk.stride(0), qk.stride(1), qk.stride(2), qk.stride(3),
             content.stride(0), content.stride(1), content.stride(2),
             kw.stride(0) if kw is not None else 0, kw.stride(1) if kw is not None else 0,
-            out.stride(0), out.stride(1), float(scale), _dtype_code(qk), _queue_ws(qk.device).data_ptr(), _stream())
+            out.stride(0), out.stride(1), float(scale), _dtype_code(qk), queue_ws.data_ptr(), _stream())
+    del queue_ws
     _check(code, 'bp_sense_mix_weighted')
     return out
 
@@ -473,12 +479,14 @@ def sense_mix_dc(qk, dout, lse, softmax_scale, like):
     `like`: the forward's content tensor (shape / dtype / device of the result)."""
     b, s, k, dk = _check_qk(qk)
     dcontent = torch.empty((b, s, k, like.shape[-1]), dtype=like.dtype, device=like.device)
+    queue_ws = _queue_ws(qk.device)
     with torch.cuda.device(qk.device):
         code = lib().bp_sense_mix_dc(
             qk.data_ptr(), dout.data_ptr(), lse.data_ptr(), dcontent.data_ptr(), b, s, k, dk, like.shape[-1],
             qk.stride(0), qk.stride(1), qk.stride(2), qk.stride(3), dout.stride(0), dout.stride(1),
             dcontent.stride(0), dcontent.stride(1), dcontent.stride(2), float(softmax_scale), _dtype_code(qk),
-            _queue_ws(qk.device).data_ptr(), _stream())
+            queue_ws.data_ptr(), _stream())
+    del queue_ws
     _check(code, 'bp_sense_mix_dc')
     return dcontent
 

@@ -19,6 +19,15 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 inline bool scale_ok(float s) { return isfinite(s) && s > 0.f; }
 
+// queue_ws == NULL means "a record of the library's own ring" (include/bp_hip.h).  A graph captured that way would
+// replay on a record every other NULL launch also cycles through, so it is refused instead of documented as unsafe.
+inline bool null_queue_ws_on_capturing_stream(const void *queue_ws, hipStream_t st) {
+    if (queue_ws != nullptr) return false;
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &status) != hipSuccess) return false;
+    return status != hipStreamCaptureStatusNone;
+}
+
 // dropout argument check shared by the *_dropout entry points: p in [0, 1), a generator state when p > 0.
 // thr: keep iff a 16-bit uniform < thr (bp_philox.h); 0 = dropout off.
 inline bool dropout_args(float p, const uint64_t *rng_state, uint32_t &thr, float &rp_keep) {
@@ -74,6 +83,8 @@ const char *bp_strerror(int code) {
         case BP_ERR_LAUNCH: return "HIP kernel launch failed";
         case BP_ERR_DOUT: return "d_out must be >= 1";
         case BP_ERR_DROPOUT: return "dropout: p must be in [0, 1), rng_state non-NULL when p > 0, 16-byte friendly shapes only";
+        case BP_ERR_QUEUE_WS: return "queue_ws must be caller-owned (non-NULL) while the stream is being captured";
+        case BP_ERR_WORKSPACE: return "workspace smaller than the *_ws_floats() query of this entry point";
         default: return "unknown error";
     }
 }
@@ -283,6 +294,7 @@ int bp_sense_mix_weighted(const void *qk, const void *content, const float *key_
     if (qk == nullptr || content == nullptr || out == nullptr || lse_ws == nullptr) return BP_ERR_SHAPE;
     if (!scale_ok(softmax_scale)) return BP_ERR_SCALE;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (null_queue_ws_on_capturing_stream(queue_ws, st)) return BP_ERR_QUEUE_WS;
     if (!lse_ready) {
         int rc = sense_lse(qk, lse_ws, batch, seqlen, nsenses, d_k, qk_batch_stride, qk_row_stride,
                            qk_two_stride, qk_sense_stride, softmax_scale, dtype, st);
@@ -331,6 +343,7 @@ int bp_sense_mix_dc(const void *qk, const void *dout, const float *lse, void *dc
     const int64_t strides[] = {qk_batch_stride, qk_row_stride, qk_sense_stride, do_batch_stride, do_row_stride,
                                c_batch_stride, c_row_stride, c_sense_stride};
     for (int64_t st : strides) if (!mult8(st)) return BP_ERR_SHAPE;
+    if (null_queue_ws_on_capturing_stream(queue_ws, static_cast<hipStream_t>(stream))) return BP_ERR_QUEUE_WS;
     bp::MixBwdParams p{};
     p.q = qp; p.k = qp + qk_two_stride; p.dout = dout; p.dc = dcontent; p.lse = lse;
     p.qk_bs = qk_batch_stride; p.qk_rs = qk_row_stride; p.qk_ss = qk_sense_stride;
@@ -378,8 +391,13 @@ int bp_sense_dq_dk(const void *qk, const void *dpt, const float *lse, float *dsu
     return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
 }
 
+int64_t bp_flash_bwd_ws_floats(int batch, int nheads, int64_t lse_stride) {
+    if (batch <= 0 || nheads <= 0 || lse_stride <= 0) return 0;
+    return (int64_t)batch * nheads * 2 * lse_stride;
+}
+
 int bp_flash_bwd(const void *dout, const void *q, const void *k, const void *v, const void *out,
-                 const float *softmax_lse, float *dsum_ws, void *dq, void *dk, void *dv,
+                 const float *softmax_lse, float *dsum_ws, int64_t dsum_ws_floats, void *dq, void *dk, void *dv,
                  const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k,
                  int batch, int nheads, int head_dim, int max_seqlen_q, int max_seqlen_k,
                  int64_t do_row_stride, int64_t do_head_stride,
@@ -392,7 +410,7 @@ int bp_flash_bwd(const void *dout, const void *q, const void *k, const void *v, 
                  int64_t dv_row_stride, int64_t dv_head_stride,
                  int64_t lse_stride, float softmax_scale, int is_causal, int dtype,
                  bp_stream_t stream) {
-    return bp_flash_bwd_dropout(dout, q, k, v, out, softmax_lse, dsum_ws, dq, dk, dv, cu_seqlens_q, cu_seqlens_k, batch,
+    return bp_flash_bwd_dropout(dout, q, k, v, out, softmax_lse, dsum_ws, dsum_ws_floats, dq, dk, dv, cu_seqlens_q, cu_seqlens_k, batch,
                                 nheads, head_dim, max_seqlen_q, max_seqlen_k, do_row_stride, do_head_stride,
                                 q_row_stride, q_head_stride, k_row_stride, k_head_stride, v_row_stride,
                                 v_head_stride, o_row_stride, o_head_stride, dq_row_stride, dq_head_stride,
@@ -401,7 +419,7 @@ int bp_flash_bwd(const void *dout, const void *q, const void *k, const void *v, 
 }
 
 int bp_flash_bwd_dropout(const void *dout, const void *q, const void *k, const void *v, const void *out,
-                 const float *softmax_lse, float *dsum_ws, void *dq, void *dk, void *dv,
+                 const float *softmax_lse, float *dsum_ws, int64_t dsum_ws_floats, void *dq, void *dk, void *dv,
                  const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k,
                  int batch, int nheads, int head_dim, int max_seqlen_q, int max_seqlen_k,
                  int64_t do_row_stride, int64_t do_head_stride,
@@ -427,6 +445,8 @@ int bp_flash_bwd_dropout(const void *dout, const void *q, const void *k, const v
                                dk_row_stride, dk_head_stride, dv_row_stride, dv_head_stride};
     for (int64_t st : strides) if (!mult8(st)) return BP_ERR_SHAPE;
     if (lse_stride % 16 != 0) return BP_ERR_SHAPE;
+    // the dQ kernel writes both statistics rows of every (batch, head): an ABI-2-sized buffer would be overrun
+    if (dsum_ws_floats < bp_flash_bwd_ws_floats(batch, nheads, lse_stride)) return BP_ERR_WORKSPACE;
 
     bp::FlashBwdParams p{};
     p.q = q; p.k = k; p.v = v; p.dout = dout; p.out = out; p.lse = softmax_lse; p.dsum = dsum_ws;

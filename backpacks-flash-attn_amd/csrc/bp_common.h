@@ -108,6 +108,17 @@ BP_DEV u32x4 ld_global_8x2B(const uint16_t *row, int col0, int ncols) {
 BP_DEV void settle(u32x4 &v) { asm volatile("" : "+v"(v)); }
 BP_DEV void settle(float &v) { asm volatile("" : "+v"(v)); }
 
+// Lane index recomputed on the spot (two VALU instructions) instead of being kept in a register from kernel entry: a
+// value every cold address computation needs is live across all the loops, and under register pressure hipcc spills
+// exactly such values -- the reload is a scratch load whose `s_waitcnt vmcnt(0)` also drains the LDS-DMA ring
+// (flash_bwd_dkdv: one such reload per edge step in front of the statistics DMA, found in the round-4 listings).
+// volatile: not hoisted, not merged with other calls.
+BP_DEV int lane_id_now() {
+    int x;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+    return x;
+}
+
 // LDS accessors on a byte offset into one shared array.
 BP_DEV u32x4 lds_read_16B(const char *smem, int off) {
     return *reinterpret_cast<const u32x4 *>(smem + off);

@@ -88,11 +88,18 @@ template <int ROW> BP_DEV int bwd_swz(int row) {
     return ROW == 128 ? ((((row >> 1) & 1) << 2) | ((row >> 2) & 3)) : (((row & 3) << 2) | ((row >> 2) & 3));
 }
 
-// per-lane source descriptor of 1-KiB piece j of a tile: tile row and first element column of the lane's 16 bytes
-template <class C> BP_DEV void piece(int wave, int lane, int j, int &row, int &col) {
-    row = (wave * C::DMA + j) * C::ROWS_PER_DMA + lane / C::SLOTS;
+// per-lane source descriptor of 1-KiB piece j of a tile: tile row and first element column of the lane's 16 bytes.
+// Piece j of wave w is piece j * NWAVE + w of the tile: a wave's pieces lie PIECE_ROWS (16 or 32) rows apart, the swizzle
+// only looks at row bits 0..3, so all of them share ONE per-lane byte offset and the piece index moves into the scalar
+// base pointer (piece_base) -- one offset register per streamed tensor instead of DMA of them.
+template <class C> BP_DEV void piece(int wave, int lane, int &row, int &col) {
+    row = wave * C::ROWS_PER_DMA + lane / C::SLOTS;
     col = ((lane % C::SLOTS) ^ bwd_swz<C::ROW>(row)) * 8;
 }
+template <class C> BP_DEV const uint16_t *piece_base(const uint16_t *tile, int j, int64_t row_stride) {
+    return tile + (int64_t)(j * C::NWAVE * C::ROWS_PER_DMA) * row_stride;
+}
+template <class C> BP_DEV int piece_lds(int wave, int j) { return (j * C::NWAVE + wave) * 1024; }
 
 // lane offsets of the two read patterns
 template <class C> BP_DEV int row_read_off(int l31, int hh, int s) {
@@ -185,17 +192,19 @@ struct DkdvCfg {
 
 // one 128-key tile `kt` of (sample, head) `bh`
 template <class ET, int KD, bool FULLD, bool DROP>
-BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32_t lds0, const int bh, const int kt,
-                                  const int pass) {
+BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32_t lds0, const int wave, const int bh,
+                                  const int kt, const int pass) {
     BWD_STAMP(1, pass, 0);
     using C = BwdCfg<KD>;
     using G = DkdvCfg<KD>;
     using E = Elem<ET>;
     constexpr int NV = C::NV;
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // (the lane index is recomputed per pass, not `threadIdx.x & 63`, and the wave index arrives as a scalar: everything
+    // derived from threadIdx.x would otherwise be hoisted in front of the two passes of a paired workgroup and live --
+    // spilled -- across the first pass's tile loops)
+    const int lane = lane_id_now();
+    const int tid = wave * 64 + lane;
     const int l31 = lane & 31;
     const int hh = lane >> 5;
 
@@ -262,35 +271,49 @@ BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32
     // ---- DMA: constant per-lane byte offsets, scalar tile pointers --------------------------------------
     const int qt_partial = (seq_q % C::BT) != 0 ? seq_q / C::BT : -1;
     const int last_row = seq_q - 1 - (seq_q / C::BT) * C::BT;
-    uint32_t q_voff[C::DMA], do_voff[C::DMA], q_voff_p[C::DMA], do_voff_p[C::DMA];
-    bool piece_live[C::DMA];
-#pragma unroll
-    for (int j = 0; j < C::DMA; ++j) {
+    // (the clamped offsets of the one partial tile a sweep can meet are recomputed from the lane's row in that cold
+    // step instead of living in registers all along: four registers the three-waves-per-SIMD bound does not have)
+    uint32_t q_voff, do_voff;
+    bool piece_live;
+    {
         int row, col;
-        piece<C>(wave, lane, j, row, col);
-        piece_live[j] = FULLD || col < p.d;
-        q_voff[j] = (uint32_t)(row * p.q_rs + col) * 2u;
-        do_voff[j] = (uint32_t)(row * p.do_rs + col) * 2u;
-        q_voff_p[j] = (uint32_t)(min(row, last_row) * p.q_rs + col) * 2u;
-        do_voff_p[j] = (uint32_t)(min(row, last_row) * p.do_rs + col) * 2u;
+        piece<C>(wave, lane, row, col);
+        piece_live = FULLD || col < p.d;
+        q_voff = (uint32_t)(row * p.q_rs + col) * 2u;
+        do_voff = (uint32_t)(row * p.do_rs + col) * 2u;
     }
+    // (a scalar int, not the bool `wave < 2`: hipcc kept a per-lane copy of the bool alive across the pass -- one more spill)
+    int stats_wave = 1 - (wave >> 1);
+    asm volatile("" : "+s"(stats_wave));
     const int64_t q_tile_stride = (int64_t)C::BT * p.q_rs, do_tile_stride = (int64_t)C::BT * p.do_rs;
     const uint16_t *qt_ptr = qg + (int64_t)qt_begin * q_tile_stride;     // tile of the NEXT issue
     const uint16_t *dot_ptr = dog + (int64_t)qt_begin * do_tile_stride;
     auto issue = [&](int qt) {
         const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + ((qt - qt_begin) % C::NSTAGE) * G::STAGE);
-        const bool partial = qt == qt_partial;
+        if (piece_live) {
+            if (__builtin_expect(qt == qt_partial, 0)) {
 #pragma unroll
-        for (int j = 0; j < C::DMA; ++j)
-            if (piece_live[j]) {
-                dma16_s(qt_ptr, partial ? q_voff_p[j] : q_voff[j],
-                        __builtin_amdgcn_readfirstlane(st + G::Q_OFF + (wave * C::DMA + j) * 1024));
-                dma16_s(dot_ptr, partial ? do_voff_p[j] : do_voff[j],
-                        __builtin_amdgcn_readfirstlane(st + G::DO_OFF + (wave * C::DMA + j) * 1024));
+                for (int j = 0; j < C::DMA; ++j) {
+                    const int row = (j * C::NWAVE + wave) * C::ROWS_PER_DMA + lane_id_now() / C::SLOTS;
+                    const uint32_t over = (uint32_t)max(row - last_row, 0);
+                    dma16_s(piece_base<C>(qt_ptr, j, p.q_rs), q_voff - over * (uint32_t)p.q_rs * 2u,
+                            __builtin_amdgcn_readfirstlane(st + G::Q_OFF + piece_lds<C>(wave, j)));
+                    dma16_s(piece_base<C>(dot_ptr, j, p.do_rs), do_voff - over * (uint32_t)p.do_rs * 2u,
+                            __builtin_amdgcn_readfirstlane(st + G::DO_OFF + piece_lds<C>(wave, j)));
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < C::DMA; ++j) {
+                    dma16_s(piece_base<C>(qt_ptr, j, p.q_rs), q_voff,
+                            __builtin_amdgcn_readfirstlane(st + G::Q_OFF + piece_lds<C>(wave, j)));
+                    dma16_s(piece_base<C>(dot_ptr, j, p.do_rs), do_voff,
+                            __builtin_amdgcn_readfirstlane(st + G::DO_OFF + piece_lds<C>(wave, j)));
+                }
             }
+        }
         // the tile's 64 x -D (wave 0) and 64 x -L/scale (wave 1); rows past the sequence: anything, they are masked
-        if (wave < 2) {
-            const float *src = stats_g + wave * p.lse_stride + min(qt * C::BT + lane, (int)p.lse_stride - 1);
+        if (stats_wave) {
+            const float *src = stats_g + wave * p.lse_stride + min(qt * C::BT + lane_id_now(), (int)p.lse_stride - 1);
             dma4(src, st + G::D_OFF + wave * 256);
         }
         qt_ptr += q_tile_stride;
@@ -402,7 +425,7 @@ BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32
     // that was read during the previous step
     auto step_begin = [&](int qt) -> const char * {
         const int ahead = min(nqt - 1 - qt, C::NSTAGE - 2);   // tiles requested after tile qt
-        if (wave < 2) ring_wait<2 * C::DMA + 1>(ahead);
+        if (stats_wave) ring_wait<2 * C::DMA + 1>(ahead);
         else ring_wait<2 * C::DMA>(ahead);
         __builtin_amdgcn_s_barrier();
         if (qt + C::NSTAGE - 1 < nqt) issue(qt + C::NSTAGE - 1);
@@ -456,7 +479,10 @@ BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32
     BWD_STAMP(1, pass, 6);   // all tiles done
 
     if (!wave_has_keys) return;
-    const int key_row = min(my_key, seq_k - 1);
+    int key_row = min(my_key, seq_k - 1);
+    // (opaque here: hipcc otherwise forms the two 64-bit output row pointers in front of the tile loops and carries --
+    // spills -- them across the clean loop)
+    asm volatile("" : "+v"(key_row));
     uint16_t *dkg = reinterpret_cast<uint16_t *>(p.dk) + (si.k_row0 + key_row) * p.dk_rs + (int64_t)head * p.dk_hs;
     uint16_t *dvg = reinterpret_cast<uint16_t *>(p.dv) + (si.k_row0 + key_row) * p.dv_rs + (int64_t)head * p.dv_hs;
     const int d_lim = my_key < seq_k ? p.d : 0;   // lanes past the sequence exchange, but store nothing
@@ -473,8 +499,8 @@ BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32
 // =====================================================================================================
 // one 128-query tile `qt` of (sample, head) `bh`
 template <class ET, int KD, bool FULLD, bool DROP>
-BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t lds0, const int bh, const int qt,
-                                const int pass) {
+BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t lds0, const int wave, const int bh,
+                                const int qt, const int pass) {
     BWD_STAMP(0, pass, 0);
     using C = BwdCfg<KD>;
     using E = Elem<ET>;
@@ -482,9 +508,11 @@ BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t
     // stage = K image | V image
     constexpr int K_OFF = 0, V_OFF = C::TILE, STAGE = 2 * C::TILE;
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // (the lane index is recomputed per pass, not `threadIdx.x & 63`, and the wave index arrives as a scalar: everything
+    // derived from threadIdx.x would otherwise be hoisted in front of the two passes of a paired workgroup and live --
+    // spilled -- across the first pass's tile loops)
+    const int lane = lane_id_now();
+    const int tid = wave * 64 + lane;
     const int l31 = lane & 31;
     const int hh = lane >> 5;
 
@@ -547,31 +575,40 @@ BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t
     // ---- DMA -----------------------------------------------------------------------------------------------
     const int kb_partial = (seq_k % C::BT) != 0 ? seq_k / C::BT : -1;
     const int last_row = seq_k - 1 - (seq_k / C::BT) * C::BT;
-    uint32_t k_voff[C::DMA], v_voff[C::DMA], k_voff_p[C::DMA], v_voff_p[C::DMA];
-    bool piece_live[C::DMA];
-#pragma unroll
-    for (int j = 0; j < C::DMA; ++j) {
+    uint32_t k_voff, v_voff;   // (one offset per tensor, see piece(); partial tile: clamped in its own cold step)
+    bool piece_live;
+    {
         int row, col;
-        piece<C>(wave, lane, j, row, col);
-        piece_live[j] = FULLD || col < p.d;
-        k_voff[j] = (uint32_t)(row * p.k_rs + col) * 2u;
-        v_voff[j] = (uint32_t)(row * p.v_rs + col) * 2u;
-        k_voff_p[j] = (uint32_t)(min(row, last_row) * p.k_rs + col) * 2u;
-        v_voff_p[j] = (uint32_t)(min(row, last_row) * p.v_rs + col) * 2u;
+        piece<C>(wave, lane, row, col);
+        piece_live = FULLD || col < p.d;
+        k_voff = (uint32_t)(row * p.k_rs + col) * 2u;
+        v_voff = (uint32_t)(row * p.v_rs + col) * 2u;
     }
     const int64_t k_tile_stride = (int64_t)C::BT * p.k_rs, v_tile_stride = (int64_t)C::BT * p.v_rs;
     const uint16_t *kt_ptr = kg, *vt_ptr = vg;
     auto issue = [&](int kb) {
         const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + (kb % C::NSTAGE) * STAGE);
-        const bool partial = kb == kb_partial;
+        if (piece_live) {
+            if (__builtin_expect(kb == kb_partial, 0)) {
 #pragma unroll
-        for (int j = 0; j < C::DMA; ++j)
-            if (piece_live[j]) {
-                dma16_s(kt_ptr, partial ? k_voff_p[j] : k_voff[j],
-                        __builtin_amdgcn_readfirstlane(st + K_OFF + (wave * C::DMA + j) * 1024));
-                dma16_s(vt_ptr, partial ? v_voff_p[j] : v_voff[j],
-                        __builtin_amdgcn_readfirstlane(st + V_OFF + (wave * C::DMA + j) * 1024));
+                for (int j = 0; j < C::DMA; ++j) {
+                    const int row = (j * C::NWAVE + wave) * C::ROWS_PER_DMA + lane_id_now() / C::SLOTS;
+                    const uint32_t over = (uint32_t)max(row - last_row, 0);
+                    dma16_s(piece_base<C>(kt_ptr, j, p.k_rs), k_voff - over * (uint32_t)p.k_rs * 2u,
+                            __builtin_amdgcn_readfirstlane(st + K_OFF + piece_lds<C>(wave, j)));
+                    dma16_s(piece_base<C>(vt_ptr, j, p.v_rs), v_voff - over * (uint32_t)p.v_rs * 2u,
+                            __builtin_amdgcn_readfirstlane(st + V_OFF + piece_lds<C>(wave, j)));
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < C::DMA; ++j) {
+                    dma16_s(piece_base<C>(kt_ptr, j, p.k_rs), k_voff,
+                            __builtin_amdgcn_readfirstlane(st + K_OFF + piece_lds<C>(wave, j)));
+                    dma16_s(piece_base<C>(vt_ptr, j, p.v_rs), v_voff,
+                            __builtin_amdgcn_readfirstlane(st + V_OFF + piece_lds<C>(wave, j)));
+                }
             }
+        }
         kt_ptr += k_tile_stride;
         vt_ptr += v_tile_stride;
     };
@@ -713,7 +750,9 @@ BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t
     BWD_STAMP(0, pass, 6);   // all tiles done
 
     if (!wave_has_rows) return;
-    uint16_t *dqg = reinterpret_cast<uint16_t *>(p.dq) + (si.q_row0 + min(my_q, seq_q - 1)) * p.dq_rs + (int64_t)head * p.dq_hs;
+    int q_row = min(my_q, seq_q - 1);
+    asm volatile("" : "+v"(q_row));   // (as in the dK/dV epilogue: keep the output pointer out of the tile loops)
+    uint16_t *dqg = reinterpret_cast<uint16_t *>(p.dq) + (si.q_row0 + q_row) * p.dq_rs + (int64_t)head * p.dq_hs;
     const int d_lim = my_q < seq_q ? p.d : 0;
 #pragma unroll
     for (int n = 0; n < NV; ++n) store_block16<E, (KD <= 4)>(dqg, dq[n], p.scale, n, hh, d_lim);
@@ -732,6 +771,7 @@ template <class ET, int KD, bool FULLD, bool DROP>
 __global__ __launch_bounds__(256, BP_BWD_DKDV_MINWAVES(KD, DROP)) void flash_bwd_dkdv_kernel(const FlashBwdParams p) {
     __shared__ __attribute__((aligned(16))) char smem[DkdvCfg<KD>::SMEM];
     const uint32_t lds0 = lds_base_addr(smem);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = (p.max_sk + 127) / 128;
     const bool pair = p.causal && n > 1;
     int bh, slot;
@@ -740,7 +780,7 @@ __global__ __launch_bounds__(256, BP_BWD_DKDV_MINWAVES(KD, DROP)) void flash_bwd
     const int npass = (pair && other != slot) ? 2 : 1;
     for (int pass = 0; pass < npass; ++pass) {
         if (pass) __syncthreads();
-        flash_bwd_dkdv_tile<ET, KD, FULLD, DROP>(p, smem, lds0, bh, pass ? other : slot, pass);
+        flash_bwd_dkdv_tile<ET, KD, FULLD, DROP>(p, smem, lds0, wave, bh, pass ? other : slot, pass);
     }
 }
 
@@ -754,6 +794,7 @@ __global__ __launch_bounds__(256, BP_BWD_DQ_MINWAVES(KD)) void flash_bwd_dq_kern
     using C = BwdCfg<KD>;
     __shared__ __attribute__((aligned(16))) char smem[C::NSTAGE * 2 * C::TILE];
     const uint32_t lds0 = lds_base_addr(smem);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = (p.max_sq + 127) / 128;
     const bool pair = p.causal && n > 1;
     int bh, slot;
@@ -762,7 +803,7 @@ __global__ __launch_bounds__(256, BP_BWD_DQ_MINWAVES(KD)) void flash_bwd_dq_kern
     const int npass = (pair && heavy != slot) ? 2 : 1;
     for (int pass = 0; pass < npass; ++pass) {
         if (pass) __syncthreads();
-        flash_bwd_dq_tile<ET, KD, FULLD, DROP>(p, smem, lds0, bh, pass ? slot : heavy, pass);
+        flash_bwd_dq_tile<ET, KD, FULLD, DROP>(p, smem, lds0, wave, bh, pass ? slot : heavy, pass);
     }
 }
 

@@ -60,26 +60,6 @@ __global__ __launch_bounds__(512) void sense_mix_dc_kernel(const MixBwdParams p)
     const float c2 = p.scale_log2e;
     const uint32_t lds0 = lds_base_addr(smem);
 
-    // ---- per-lane DMA source descriptors, job-invariant parts ------------------------------------------
-    int q_row[C::Q_DMA];
-    uint32_t q_col[C::Q_DMA];
-#pragma unroll
-    for (int j = 0; j < C::Q_DMA; ++j) {
-        const int row = (wave * C::Q_DMA + j) * C::Q_ROWS_PER_DMA + lane / C::QSLOTS;
-        const int logical = (lane % C::QSLOTS) ^ k_swz<C::QROW>(row);
-        q_row[j] = row;
-        q_col[j] = logical * 8 < p.dk ? logical * 8 : 0;   // pad slot: a duplicate of column 0 (meets zero K columns)
-    }
-    int d_row[C::D_DMA];
-    uint32_t d_col[C::D_DMA];
-#pragma unroll
-    for (int j = 0; j < C::D_DMA; ++j) {
-        const int row = (wave * C::D_DMA + j) * 2 + (lane >> 5);
-        const int stored = lane & 31;
-        const int logical = (((stored >> 2) ^ (row & 3)) << 2) | (stored & 3);
-        d_row[j] = row;
-        d_col[j] = logical * 8;
-    }
     int q_read_off[KD];   // Q fragment (A operand of S = Q K^T): row l31 (+32*kk), logical slot 2*s + hh
 #pragma unroll
     for (int s = 0; s < KD; ++s) q_read_off[s] = l31 * C::QROW + (((2 * s + hh) ^ k_swz<C::QROW>(l31)) * 16);
@@ -140,19 +120,30 @@ __global__ __launch_bounds__(512) void sense_mix_dc_kernel(const MixBwdParams p)
         const int qb_clean = min(qb_begin + C::BM / C::BQ, nqb);
         const int nq = nqb - qb_begin;
 
+        // Per-lane byte offsets of my DMA pieces inside a tile, rebuilt per job from an opaque copy of the lane index so
+        // that the row / column tables are not hoisted to kernel entry and kept alive (and spilled) across the job loop;
+        // the partial last tile clamps its rows inside issue(), in a cold branch (see sense_mix_dma.hip).
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
         const int qb_partial = (S % C::BQ) != 0 ? nqb - 1 : -1;
         const int last_row = S - 1 - (nqb - 1) * C::BQ;
-        uint32_t q_voff[C::Q_DMA], d_voff[C::D_DMA], q_voff_p[C::Q_DMA], d_voff_p[C::D_DMA];
+        auto q_piece_row = [&](int j) { return (wave * C::Q_DMA + j) * C::Q_ROWS_PER_DMA + lane_o / C::QSLOTS; };
+        auto d_piece_row = [&](int j) { return (wave * C::D_DMA + j) * 2 + (lane_o >> 5); };
+        uint32_t q_voff[C::Q_DMA], d_voff[C::D_DMA];
 #pragma unroll
         for (int j = 0; j < C::Q_DMA; ++j) {
-            q_voff[j] = (uint32_t)(q_row[j] * p.qk_rs + q_col[j]) * 2u;
-            q_voff_p[j] = (uint32_t)(min(q_row[j], last_row) * p.qk_rs + q_col[j]) * 2u;
+            const int row = q_piece_row(j);
+            const int logical = (lane_o % C::QSLOTS) ^ k_swz<C::QROW>(row);
+            const int col = logical * 8 < p.dk ? logical * 8 : 0;   // pad slot: a duplicate of column 0 (meets zero K columns)
+            q_voff[j] = (uint32_t)(row * p.qk_rs + col) * 2u;
         }
 #pragma unroll
         for (int j = 0; j < C::D_DMA; ++j) {
-            const uint32_t col = (FULL || col_base + (int)d_col[j] < p.dout_cols) ? col_base + d_col[j] : col_base;
-            d_voff[j] = (uint32_t)(d_row[j] * p.do_rs + col) * 2u;
-            d_voff_p[j] = (uint32_t)(min(d_row[j], last_row) * p.do_rs + col) * 2u;
+            const int row = d_piece_row(j);
+            const int stored = lane_o & 31;
+            const int logical = (((stored >> 2) ^ (row & 3)) << 2) | (stored & 3);
+            const int col = (FULL || col_base + logical * 8 < p.dout_cols) ? col_base + logical * 8 : col_base;
+            d_voff[j] = (uint32_t)(row * p.do_rs + col) * 2u;
         }
 
         // DMA pieces of the tile two steps ahead, (l2, qb2); its base pointers are carried and advanced on the scalar unit
@@ -164,15 +155,29 @@ __global__ __launch_bounds__(512) void sense_mix_dc_kernel(const MixBwdParams p)
         const uint16_t *dt2 = dg + (int64_t)qb_begin * d_tile_step;
         auto issue = [&](int, int, int slot, uint32_t pieces) {
             const uint32_t stage_off = lds0 + slot * C::STAGE;
-            const bool partial = qb2 == qb_partial;
+            if (__builtin_expect(qb2 == qb_partial, 0)) {
 #pragma unroll
-            for (int j = 0; j < C::Q_DMA; ++j)
-                if ((pieces >> j) & 1u)
-                    dma16_s(qt2, partial ? q_voff_p[j] : q_voff[j], stage_off + (wave * C::Q_DMA + j) * 1024);
+                for (int j = 0; j < C::Q_DMA; ++j)
+                    if ((pieces >> j) & 1u) {
+                        const uint32_t back = (uint32_t)(max(q_piece_row(j) - last_row, 0) * p.qk_rs) * 2u;
+                        dma16_s(qt2, q_voff[j] - back, __builtin_amdgcn_readfirstlane(stage_off + (wave * C::Q_DMA + j) * 1024));
+                    }
 #pragma unroll
-            for (int j = 0; j < C::D_DMA; ++j)
-                if ((pieces >> (C::Q_DMA + j)) & 1u)
-                    dma16_s(dt2, partial ? d_voff_p[j] : d_voff[j], stage_off + C::QTILE + (wave * C::D_DMA + j) * 1024);
+                for (int j = 0; j < C::D_DMA; ++j)
+                    if ((pieces >> (C::Q_DMA + j)) & 1u) {
+                        const uint32_t back = (uint32_t)(max(d_piece_row(j) - last_row, 0) * p.do_rs) * 2u;
+                        dma16_s(dt2, d_voff[j] - back,
+                                __builtin_amdgcn_readfirstlane(stage_off + C::QTILE + (wave * C::D_DMA + j) * 1024));
+                    }
+            } else {
+#pragma unroll
+                for (int j = 0; j < C::Q_DMA; ++j)
+                    if ((pieces >> j) & 1u) dma16_s(qt2, q_voff[j], stage_off + (wave * C::Q_DMA + j) * 1024);
+#pragma unroll
+                for (int j = 0; j < C::D_DMA; ++j)
+                    if ((pieces >> (C::Q_DMA + j)) & 1u)
+                        dma16_s(dt2, d_voff[j], stage_off + C::QTILE + (wave * C::D_DMA + j) * 1024);
+            }
             if ((pieces >> (C::Q_DMA + C::D_DMA)) & 1u) {
                 // lse of the tile's 64 queries for sense l2: lane i fetches lse[q0 + i] into the wave's own 256-B slot
                 const float *src = p.lse + ((int64_t)batch * p.nsenses + l2) * p.lse_stride + min(qb2 * C::BQ + lane, S - 1);

@@ -85,28 +85,6 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
     const float c2 = p.scale_log2e;
     const uint32_t lds0 = lds_base_addr(smem);
 
-    // ---- per-lane DMA source descriptors, job-invariant parts ------------------------------------------
-    // K piece j of this wave: rows (wave*K_DMA + j)*RPD + lane/KSLOTS, stored slot lane%KSLOTS
-    int k_row[C::K_DMA];
-    uint32_t k_col[C::K_DMA];
-#pragma unroll
-    for (int j = 0; j < C::K_DMA; ++j) {
-        const int row = (wave * C::K_DMA + j) * C::K_ROWS_PER_DMA + lane / C::KSLOTS;
-        const int logical = (lane % C::KSLOTS) ^ k_swz<C::KROW>(row);
-        k_row[j] = row;
-        k_col[j] = logical * 8 < p.dk ? logical * 8 : 0;   // pad slot: a duplicate of column 0 (finite)
-    }
-    // C piece j of this wave: rows (wave*C_DMA + j)*2 + lane/32, stored chunk lane%32
-    int c_row[C::C_DMA];
-    uint32_t c_col[C::C_DMA];
-#pragma unroll
-    for (int j = 0; j < C::C_DMA; ++j) {
-        const int row = (wave * C::C_DMA + j) * 2 + (lane >> 5);
-        const int stored = lane & 31;
-        const int logical = (((stored >> 2) ^ (row & 3)) << 2) | (stored & 3);
-        c_row[j] = row;
-        c_col[j] = logical * 8;
-    }
     // lane-constant LDS read offsets
     int k_read_off[KD];   // K fragment (A operand of S^T): row l31 (+32*kk), logical slot 2*s + hh
 #pragma unroll
@@ -179,22 +157,34 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
         const int my_diag_sub = q0 >> 5;   // index of the 32-key sub-block that holds my diagonal
         const int nb_live = FULL ? C::NB : min(C::NB, (p.dout - col_base + 31) / 32);
 
-        // per-lane byte offsets of my pieces inside a tile (the scalar tile base is added by the DMA instruction):
-        // one set for full tiles, one for the job's only possible partial tile (the last one, when the sequence
-        // ends inside it; its rows are clamped to the final valid key).  A uniform select per piece, no branch.
+        // Per-lane byte offsets of my DMA pieces inside a tile (the scalar tile base is added by the DMA instruction).
+        // K piece j of this wave: rows (wave*K_DMA + j)*RPD + lane/KSLOTS, stored slot lane%KSLOTS; C piece j: rows
+        // (wave*C_DMA + j)*2 + lane/32, stored chunk lane%32.  They are rebuilt PER JOB from an opaque copy of the lane
+        // index: as loop invariants hipcc hoists the row / column tables to kernel entry and keeps them alive across
+        // the whole job loop -- ten registers that the d_k = 48 instantiation then spilled to scratch (round-3 review).
+        // The job's only possible partial tile (the last one, when the sequence ends inside it) clamps its rows to the
+        // final valid key inside issue(), in a cold branch, instead of carrying a second offset set.
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
         const int kb_partial = (k_end == S && (S % C::BK) != 0) ? nkb - 1 : -1;
         const int last_row = S - 1 - (nkb - 1) * C::BK;
-        uint32_t k_voff[C::K_DMA], c_voff[C::C_DMA], k_voff_p[C::K_DMA], c_voff_p[C::C_DMA];
+        auto k_piece_row = [&](int j) { return (wave * C::K_DMA + j) * C::K_ROWS_PER_DMA + lane_o / C::KSLOTS; };
+        auto c_piece_row = [&](int j) { return (wave * C::C_DMA + j) * 2 + (lane_o >> 5); };
+        uint32_t k_voff[C::K_DMA], c_voff[C::C_DMA];
 #pragma unroll
         for (int j = 0; j < C::K_DMA; ++j) {
-            k_voff[j] = (uint32_t)(k_row[j] * p.qk_rs + k_col[j]) * 2u;
-            k_voff_p[j] = (uint32_t)(min(k_row[j], last_row) * p.qk_rs + k_col[j]) * 2u;
+            const int row = k_piece_row(j);
+            const int logical = (lane_o % C::KSLOTS) ^ k_swz<C::KROW>(row);
+            const int col = logical * 8 < p.dk ? logical * 8 : 0;   // pad slot: a duplicate of column 0 (finite)
+            k_voff[j] = (uint32_t)(row * p.qk_rs + col) * 2u;
         }
 #pragma unroll
         for (int j = 0; j < C::C_DMA; ++j) {
-            const uint32_t col = (FULL || col_base + (int)c_col[j] < p.dout) ? col_base + c_col[j] : col_base;
-            c_voff[j] = (uint32_t)(c_row[j] * p.c_rs + col) * 2u;
-            c_voff_p[j] = (uint32_t)(min(c_row[j], last_row) * p.c_rs + col) * 2u;
+            const int row = c_piece_row(j);
+            const int stored = lane_o & 31;
+            const int logical = (((stored >> 2) ^ (row & 3)) << 2) | (stored & 3);
+            const int col = (FULL || col_base + logical * 8 < p.dout) ? col_base + logical * 8 : col_base;
+            c_voff[j] = (uint32_t)(row * p.c_rs + col) * 2u;
         }
 
         // DMA pieces of the tile two steps ahead, (l2, kb2), into ring slot `slot`; `pieces` selects a subset (bit j).
@@ -206,16 +196,30 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
         const int64_t k_tile_step = (int64_t)C::BK * p.qk_rs, c_tile_step = (int64_t)C::BK * p.c_rs;
         auto issue = [&](int, int, int slot, uint32_t pieces) {
             const uint32_t stage_off = lds0 + slot * C::STAGE;
-            const bool partial = kb2 == kb_partial;
+            if (__builtin_expect(kb2 == kb_partial, 0)) {
 #pragma unroll
-            for (int j = 0; j < C::K_DMA; ++j)
-                if ((pieces >> j) & 1u)
-                    dma16_s(kt2, partial ? k_voff_p[j] : k_voff[j], stage_off + (wave * C::K_DMA + j) * 1024);
+                for (int j = 0; j < C::K_DMA; ++j)
+                    if ((pieces >> j) & 1u) {
+                        const uint32_t back = (uint32_t)(max(k_piece_row(j) - last_row, 0) * p.qk_rs) * 2u;
+                        dma16_s(kt2, k_voff[j] - back, __builtin_amdgcn_readfirstlane(stage_off + (wave * C::K_DMA + j) * 1024));
+                    }
 #pragma unroll
-            for (int j = 0; j < C::C_DMA; ++j)
-                if ((pieces >> (C::K_DMA + j)) & 1u)
-                    // the content stream is read once per job: non-temporal (-1.6 % at B=64, r02_p)
-                    dma16_s_nt(ct2, partial ? c_voff_p[j] : c_voff[j], stage_off + C::KTILE + (wave * C::C_DMA + j) * 1024);
+                for (int j = 0; j < C::C_DMA; ++j)
+                    if ((pieces >> (C::K_DMA + j)) & 1u) {
+                        const uint32_t back = (uint32_t)(max(c_piece_row(j) - last_row, 0) * p.c_rs) * 2u;
+                        dma16_s_nt(ct2, c_voff[j] - back,
+                                   __builtin_amdgcn_readfirstlane(stage_off + C::KTILE + (wave * C::C_DMA + j) * 1024));
+                    }
+            } else {
+#pragma unroll
+                for (int j = 0; j < C::K_DMA; ++j)
+                    if ((pieces >> j) & 1u) dma16_s(kt2, k_voff[j], stage_off + (wave * C::K_DMA + j) * 1024);
+#pragma unroll
+                for (int j = 0; j < C::C_DMA; ++j)
+                    if ((pieces >> (C::K_DMA + j)) & 1u)
+                        // the content stream is read once per job: non-temporal (-1.6 % at B=64, r02_p)
+                        dma16_s_nt(ct2, c_voff[j], stage_off + C::KTILE + (wave * C::C_DMA + j) * 1024);
+            }
             if (WEIGHTED && ((pieces >> (C::K_DMA + C::C_DMA)) & 1u)) {
                 // key weights of this (sense, tile): lane i fetches w[key0 + i] into the wave's own 256-B slot
                 const float *src = p.kw + batch * p.kw_bs + (int64_t)l2 * p.kw_ss + min(kb2 * C::BK + lane, S - 1);

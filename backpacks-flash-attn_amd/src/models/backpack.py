@@ -112,15 +112,25 @@ class ContextSelfAttn(nn.Module):
         graph (gradients flow back to the unpadded parameter); without it (inference) the padded copy is kept until the
         parameter changes -- `_version` moves on every in-place update, `data_ptr` on a reload / `.to()`."""
         weight, bias = self.Wqkv.weight, self.Wqkv.bias
-        if torch.is_grad_enabled() and (weight.requires_grad or bias.requires_grad):
+
+        def pad_now():
             return (F.pad(weight.view(2, k, dk, d), (0, 0, 0, pad)).view(2 * k * (dk + pad), d),
                     F.pad(bias.view(2, k, dk), (0, pad)).view(-1))
+
+        if torch.is_grad_enabled() and (weight.requires_grad or bias.requires_grad):
+            return pad_now()
+        # While a HIP graph is being captured the pad kernels must be PART of the graph: a cached copy made outside
+        # (e.g. by GraphedForward's warm-up forwards) would be what every replay reads, also after the weights were
+        # updated in place.  Inference tensors carry no version counter: nothing to key a cache on, pad per call.
+        if (weight.is_cuda and torch.cuda.is_current_stream_capturing()) or weight.is_inference() \
+                or bias.is_inference():
+            with torch.no_grad():
+                return pad_now()
         key = (weight.data_ptr(), weight._version, bias.data_ptr(), bias._version, weight.dtype, weight.device)
         cached = getattr(self, '_padded_cache', None)
         if cached is None or cached[0] != key:
             with torch.no_grad():
-                cached = (key, F.pad(weight.view(2, k, dk, d), (0, 0, 0, pad)).view(2 * k * (dk + pad), d),
-                          F.pad(bias.view(2, k, dk), (0, pad)).view(-1))
+                cached = (key,) + pad_now()
             self._padded_cache = cached
         return cached[1], cached[2]
 

@@ -12,8 +12,9 @@
  *     record of device memory, `queue_ws` (BP_QUEUE_WS_BYTES, 16-byte aligned, contents undefined on entry: a
  *     memset node in front of the kernel zeroes it on the stream; it must belong to this launch alone until the
  *     launch has completed -- so a captured HIP graph owns the record it replays).  queue_ws == NULL takes the next
- *     record of a 64-entry ring owned by the library: fine for eager launches, NOT for graph capture or for more
- *     than 64 launches in flight,
+ *     record of a 64-entry ring owned by the library: fine for eager launches with fewer than 64 of them in flight;
+ *     a NULL queue_ws on a stream that is being captured returns BP_ERR_QUEUE_WS (a replayed graph would share the
+ *     library's record with every other launch),
  *   - enqueue on the given hipStream_t and return without synchronising,
  *   - return 0 on success or a negative BP_ERR_* (the Python layer raises RuntimeError, which
  *     is what TORCH_CHECK failures surface as in the reference: fmha_api.cpp:206-250).
@@ -27,8 +28,10 @@
 extern "C" {
 #endif
 
-#define BP_ABI_VERSION 3   /* 2: *_dropout entry points added; 3: bias/GELU + column-sum entry points added, the
-                              persistent sense-mix launches take a caller-owned `queue_ws` */
+#define BP_ABI_VERSION 4   /* 2: *_dropout entry points added; 3: bias/GELU + column-sum entry points added, the
+                              persistent sense-mix launches take a caller-owned `queue_ws`; 4: bp_flash_bwd* take the
+                              size of `dsum_ws` (bp_flash_bwd_ws_floats) and check it, queue_ws == NULL is refused
+                              while the stream is capturing (BP_ERR_QUEUE_WS) */
 
 /* element type of q/k/v/out/content tensors */
 #define BP_DTYPE_F16 0
@@ -43,6 +46,8 @@ extern "C" {
 #define BP_ERR_LAUNCH -5      /* hipLaunchKernel failed (FMHA_CHECK_CUDA, src/fmha_utils.h:39)              */
 #define BP_ERR_DOUT -6        /* sense mix: d_out < 1                                                       */
 #define BP_ERR_DROPOUT -7     /* p_dropout outside [0,1), rng_state NULL with p > 0, or a shape the dropout path lacks */
+#define BP_ERR_QUEUE_WS -8    /* persistent launch with queue_ws == NULL on a stream that is being captured            */
+#define BP_ERR_WORKSPACE -9   /* a caller-provided workspace is smaller than the entry point's *_ws_floats() query     */
 
 #define BP_QUEUE_WS_BYTES 64   /* `queue_ws` of the persistent sense-mix launches */
 
@@ -258,11 +263,15 @@ int bp_sense_dq_dk(const void *qk, const void *dpt, const float *lse, float *dsu
  *   softmax_lse  (batch, nheads, lse_stride) fp32
  *   dsum_ws      (batch, nheads, 2, lse_stride) fp32 workspace, contents undefined on entry: the kernels put the row
  *                statistics there, -D[b,h,i] = -sum_d dout_i[d] * out_i[d] (upstream's dsoftmax_sum,
- *                fmha_api.cpp:421) and -softmax_lse[b,h,i] / softmax_scale  (ABI 3: twice the ABI-2 size)
+ *                fmha_api.cpp:421) and -softmax_lse[b,h,i] / softmax_scale
+ *   dsum_ws_floats  number of floats `dsum_ws` holds; must be >= bp_flash_bwd_ws_floats(batch, nheads, lse_stride)
+ *                (BP_ERR_WORKSPACE otherwise: the workspace doubled between ABI 2 and 3, so its size is now an
+ *                argument instead of a sentence in this comment)
  *   cu_seqlens_*       as in bp_flash_fwd (NULL = fixed length)
  */
+int64_t bp_flash_bwd_ws_floats(int batch, int nheads, int64_t lse_stride);
 int bp_flash_bwd(const void *dout, const void *q, const void *k, const void *v, const void *out,
-                 const float *softmax_lse, float *dsum_ws, void *dq, void *dk, void *dv,
+                 const float *softmax_lse, float *dsum_ws, int64_t dsum_ws_floats, void *dq, void *dk, void *dv,
                  const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k,
                  int batch, int nheads, int head_dim, int max_seqlen_q, int max_seqlen_k,
                  int64_t do_row_stride, int64_t do_head_stride,
@@ -283,7 +292,7 @@ int bp_flash_bwd(const void *dout, const void *q, const void *k, const void *v, 
  * (p_dropout, rng_state) the forward's; the kernels regenerate the mask.
  */
 int bp_flash_bwd_dropout(const void *dout, const void *q, const void *k, const void *v, const void *out,
-                         const float *softmax_lse, float *dsum_ws, void *dq, void *dk, void *dv,
+                         const float *softmax_lse, float *dsum_ws, int64_t dsum_ws_floats, void *dq, void *dk, void *dv,
                          const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k,
                          int batch, int nheads, int head_dim, int max_seqlen_q, int max_seqlen_k,
                          int64_t do_row_stride, int64_t do_head_stride,

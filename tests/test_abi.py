@@ -79,18 +79,26 @@ def test_argument_validation_returns_before_any_launch():
                            null) == -3
     # backward: head dim the kernel does not cover, bad dtype, null dq, odd lse stride
     st = [64] * 16
-    assert h.bp_flash_bwd(p, p, p, p, p, p, p, p, p, p, null, null, 1, 1, 136, 16, 16, *st, 16, 0.125, 1, 1,
+    assert h.bp_flash_bwd(p, p, p, p, p, p, p, 64, p, p, p, null, null, 1, 1, 136, 16, 16, *st, 16, 0.125, 1, 1,
                           null) == -2
-    assert h.bp_flash_bwd(p, p, p, p, p, p, p, p, p, p, null, null, 1, 1, 64, 16, 16, *st, 16, 0.125, 1, 5,
+    assert h.bp_flash_bwd(p, p, p, p, p, p, p, 64, p, p, p, null, null, 1, 1, 64, 16, 16, *st, 16, 0.125, 1, 5,
                           null) == -1
-    assert h.bp_flash_bwd(p, p, p, p, p, p, p, null, p, p, null, null, 1, 1, 64, 16, 16, *st, 16, 0.125, 1, 1,
+    assert h.bp_flash_bwd(p, p, p, p, p, p, p, 64, null, p, p, null, null, 1, 1, 64, 16, 16, *st, 16, 0.125, 1, 1,
                           null) == -3
-    assert h.bp_flash_bwd(p, p, p, p, p, p, p, p, p, p, null, null, 1, 1, 64, 16, 16, *st, 17, 0.125, 1, 1,
+    assert h.bp_flash_bwd(p, p, p, p, p, p, p, 64, p, p, p, null, null, 1, 1, 64, 16, 16, *st, 17, 0.125, 1, 1,
                           null) == -3
-    assert h.bp_flash_bwd(p, p, p, p, p, p, p, p, p, p, null, null, 1, 1, 64, 16, 16, *st, 16, -1.0, 1, 1,
+    assert h.bp_flash_bwd(p, p, p, p, p, p, p, 64, p, p, p, null, null, 1, 1, 64, 16, 16, *st, 16, -1.0, 1, 1,
                           null) == -4
-    assert h.bp_flash_bwd_dropout(p, p, p, p, p, p, p, p, p, p, null, null, 1, 1, 64, 16, 16, *st, 16, 0.125, 1, 1,
+    assert h.bp_flash_bwd_dropout(p, p, p, p, p, p, p, 64, p, p, p, null, null, 1, 1, 64, 16, 16, *st, 16, 0.125, 1, 1,
                                   0.5, null, null) == -7
+    # the statistics workspace is (batch, nheads, 2, lse_stride) floats since ABI 3; an ABI-2-sized buffer (half of
+    # it) must be refused, not overrun (ABI 4: the size is an argument, bp_flash_bwd_ws_floats is the query)
+    assert h.bp_flash_bwd_ws_floats(3, 5, 1024) == 3 * 5 * 2 * 1024
+    assert h.bp_flash_bwd_ws_floats(0, 5, 1024) == 0
+    assert h.bp_flash_bwd(p, p, p, p, p, p, p, 16, p, p, p, null, null, 1, 1, 64, 16, 16, *st, 16, 0.125, 1, 1,
+                          null) == -9
+    assert h.bp_flash_bwd(p, p, p, p, p, p, p, 31, p, p, p, null, null, 1, 1, 64, 16, 16, *st, 16, 0.125, 1, 1,
+                          null) == -9
     assert h.bp_attn_probs_dropout(p, p, p, p, 1, 1, 64, 16, 16, 1, 1, 1, 1, 1, 1, 16, 1, 1, 1, 0.125, 1, 1,
                                    2.0, p, null) == -7
 

@@ -365,3 +365,33 @@ def test_padded_sense_projection_is_cached_in_inference_and_tracks_the_parameter
     out.square().sum().backward()
     assert attn.Wqkv.weight.grad is not None and attn.Wqkv.weight.grad.shape == attn.Wqkv.weight.shape
     assert '_padded_cache' not in attn.state_dict()
+
+
+def test_padded_sense_projection_with_inference_tensors():
+    """Parameters created under torch.inference_mode carry no version counter (reading `._version` raises): the pad then
+    runs per call instead of being cached (advisor, round 3)."""
+    from src.models.backpack import ContextSelfAttn
+    with torch.inference_mode():
+        attn = ContextSelfAttn(8, 80, use_hip=True)
+        x = torch.randn(2, 5, 80)
+        a = attn.project(x)
+        assert a.shape == (2, 5, 2, 8, 16) and torch.count_nonzero(a[..., 10:]) == 0
+        assert getattr(attn, '_padded_cache', None) is None
+        plain = torch.nn.functional.linear(x, attn.Wqkv.weight, attn.Wqkv.bias).reshape(2, 5, 2, 8, 10)
+        assert torch.equal(a[..., :10], plain)
+
+
+def test_integration_doc_asserts_the_header_abi_version():
+    """INTEGRATION.md shows the reference-side binding; the version it asserts must be the header's (round-3 review:
+    the doc still said 2 while the header was at 3)."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, 'include', 'bp_hip.h')).read()
+    version = int(re.search(r'#define BP_ABI_VERSION (\d+)', header).group(1))
+    doc = open(os.path.join(root, 'INTEGRATION.md')).read()
+    asserted = [int(m) for m in re.findall(r'bp_abi_version\(\)`?\s*=+\s*(\d+)', doc)]
+    assert len(asserted) >= 2, 'INTEGRATION.md no longer states the ABI version'
+    assert all(v == version for v in asserted), (asserted, version)
+    import bp_hip
+    assert bp_hip.ABI_VERSION == version
