@@ -43,9 +43,10 @@ def _stamp():
     return h.hexdigest()
 
 
-def build(force=False, verbose=False, extra_flags=(), lib=LIB, tag=''):
+def build(force=False, verbose=False, extra_flags=(), lib=LIB, tag='', csrc=CSRC):
     """`extra_flags` / `lib` / `tag` build an experimental variant next to the default library
-    (A/B measurements: BP_HIP_LIB=<path> selects it at run time)."""
+    (A/B measurements: BP_HIP_LIB=<path> selects it at run time); `csrc`: take the sources from another directory
+    (e.g. an earlier revision's kernels checked out next to the tree, `--src-dir`)."""
     out_dir = OUT_DIR + tag
     os.makedirs(out_dir, exist_ok=True)
     stamp_file = os.path.join(out_dir, 'stamp.txt')
@@ -58,7 +59,7 @@ def build(force=False, verbose=False, extra_flags=(), lib=LIB, tag=''):
 
     def compile_one(src):
         obj = os.path.join(out_dir, src.replace('.hip', '.o'))
-        cmd = [hipcc] + FLAGS + list(extra_flags) + ['-c', os.path.join(CSRC, src), '-o', obj]
+        cmd = [hipcc] + FLAGS + list(extra_flags) + ['-c', os.path.join(csrc, src), '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stderr[-8000:]))
@@ -82,8 +83,9 @@ def build(force=False, verbose=False, extra_flags=(), lib=LIB, tag=''):
 if __name__ == '__main__':
     if '--variant' in sys.argv:   # python build_hip.py --variant NAME -- <extra hipcc flags>
         name = sys.argv[sys.argv.index('--variant') + 1]
-        extra = sys.argv[sys.argv.index('--') + 1:]
-        print(build(force=True, verbose=True, extra_flags=extra, tag='_' + name,
+        extra = sys.argv[sys.argv.index('--') + 1:] if '--' in sys.argv else []
+        src = sys.argv[sys.argv.index('--src-dir') + 1] if '--src-dir' in sys.argv else CSRC
+        print(build(force=True, verbose=True, extra_flags=extra, tag='_' + name, csrc=os.path.abspath(src),
                     lib=LIB.replace('.so', '_' + name + '.so')))
     else:
         print(build(force='--force' in sys.argv, verbose=True))

@@ -294,11 +294,14 @@ BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32
             if (__builtin_expect(qt == qt_partial, 0)) {
 #pragma unroll
                 for (int j = 0; j < C::DMA; ++j) {
-                    const int row = (j * C::NWAVE + wave) * C::ROWS_PER_DMA + lane_id_now() / C::SLOTS;
-                    const uint32_t over = (uint32_t)max(row - last_row, 0);
-                    dma16_s(piece_base<C>(qt_ptr, j, p.q_rs), q_voff - over * (uint32_t)p.q_rs * 2u,
+                    // rows past the sequence's last one re-read it; the offset is taken from the TILE base here (from
+                    // the piece base it could come out negative, and the instruction adds it unsigned)
+                    int row, col;
+                    piece<C>(wave, lane_id_now(), row, col);
+                    row = min(row + j * C::NWAVE * C::ROWS_PER_DMA, last_row);
+                    dma16_s(qt_ptr, (uint32_t)(row * p.q_rs + col) * 2u,
                             __builtin_amdgcn_readfirstlane(st + G::Q_OFF + piece_lds<C>(wave, j)));
-                    dma16_s(piece_base<C>(dot_ptr, j, p.do_rs), do_voff - over * (uint32_t)p.do_rs * 2u,
+                    dma16_s(dot_ptr, (uint32_t)(row * p.do_rs + col) * 2u,
                             __builtin_amdgcn_readfirstlane(st + G::DO_OFF + piece_lds<C>(wave, j)));
                 }
             } else {
@@ -592,11 +595,12 @@ BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t
             if (__builtin_expect(kb == kb_partial, 0)) {
 #pragma unroll
                 for (int j = 0; j < C::DMA; ++j) {
-                    const int row = (j * C::NWAVE + wave) * C::ROWS_PER_DMA + lane_id_now() / C::SLOTS;
-                    const uint32_t over = (uint32_t)max(row - last_row, 0);
-                    dma16_s(piece_base<C>(kt_ptr, j, p.k_rs), k_voff - over * (uint32_t)p.k_rs * 2u,
+                    int row, col;   // (offset from the TILE base, see the dK/dV kernel)
+                    piece<C>(wave, lane_id_now(), row, col);
+                    row = min(row + j * C::NWAVE * C::ROWS_PER_DMA, last_row);
+                    dma16_s(kt_ptr, (uint32_t)(row * p.k_rs + col) * 2u,
                             __builtin_amdgcn_readfirstlane(st + K_OFF + piece_lds<C>(wave, j)));
-                    dma16_s(piece_base<C>(vt_ptr, j, p.v_rs), v_voff - over * (uint32_t)p.v_rs * 2u,
+                    dma16_s(vt_ptr, (uint32_t)(row * p.v_rs + col) * 2u,
                             __builtin_amdgcn_readfirstlane(st + V_OFF + piece_lds<C>(wave, j)));
                 }
             } else {
