@@ -6,6 +6,7 @@ reference's pybind layer used ATen for: device memory, the current stream and ou
 missing or a call fails, a RuntimeError is raised (the reference raises ImportError /
 RuntimeError in the same situations, flash_attn/flash_attn_interface.py:5).
 """
+import contextlib
 import ctypes
 import os
 
@@ -16,6 +17,29 @@ LIB_PATH = os.environ.get('BP_HIP_LIB') or os.path.join(_HERE, 'libbackpack_hip.
 ABI_VERSION = 4
 
 _lib = None
+
+# Backward routes that are NOT the fused HIP kernels -- autograd through an eager recomputation of the attention for head
+# dims the HIP backward lacks (flash_attn_interface._FlashAttnFuncBase._bwd), the alpha-rebuilding backward of the sense
+# mix for key-weighted / non-multiple-of-8 shapes (_sense_mix_backward_rebuild) -- are opt-in: without
+# `with bp_hip.allow_eager_fallback():` they raise instead of running silently (round-3 review: "no fallback" must mean it).
+_eager_fallback = False
+
+
+@contextlib.contextmanager
+def allow_eager_fallback(enabled=True):
+    """Within the block, backward passes whose shape the fused HIP kernels do not take may use the slower routes named
+    above (they need (B, k, S, S)-sized buffers / eager attention).  The flag is read when BACKWARD runs."""
+    global _eager_fallback
+    previous, _eager_fallback = _eager_fallback, bool(enabled)
+    try:
+        yield
+    finally:
+        _eager_fallback = previous
+
+
+def eager_fallback_allowed():
+    return _eager_fallback
+
 
 _i32, _i64, _f32, _ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -553,6 +577,11 @@ class SenseMixFn(torch.autograd.Function):
         qk, content, lse, key_weight = ctx.saved_tensors
         dout = dout.contiguous()
         if not _fused_mix_backward_ok(qk, content, key_weight):
+            if not eager_fallback_allowed():
+                raise RuntimeError(
+                    'bp_hip.SenseMixFn.backward: the fused backward kernels take d_k % 8 == 0, d_out % 8 == 0, a contiguous '
+                    '(B,S,k,d) content and no key_weight; this call would take the alpha-rebuilding route (two (B,k,S,S) '
+                    'buffers + BLAS GEMMs).  Opt in with `with bp_hip.allow_eager_fallback():` around backward().')
             return _sense_mix_backward_rebuild(ctx, qk, content, lse, key_weight, dout)
         dcontent = sense_mix_dc(qk, dout, lse, ctx.scale, content) if ctx.needs_input_grad[1] else None
         dqk = sense_dqk(qk, content, dout, lse, ctx.scale) if ctx.needs_input_grad[0] else None

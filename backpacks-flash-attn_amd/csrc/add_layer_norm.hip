@@ -55,8 +55,36 @@ template <class ET, bool F32> BP_DEV void store4(void *base, int64_t idx, const 
     }
 }
 
+// Streaming (non-temporal) forms for the forward's row data: every byte is touched once per launch.  BP_LN_NT selects
+// which accesses carry the hint (development A/B: 0 none, 1 stores, 2 loads and stores, 3 loads); the launcher picks per
+// call (see launch_flags).
+template <class ET, bool F32, bool NT> BP_DEV void load4s(const void *base, int64_t idx, float (&v)[4]) {
+    if constexpr (!NT) {
+        load4<ET, F32>(base, idx, v);
+    } else if constexpr (F32) {
+        const u32x4 w = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(static_cast<const char *>(base) + idx * 4));
+        v[0] = as_f32(w[0]); v[1] = as_f32(w[1]); v[2] = as_f32(w[2]); v[3] = as_f32(w[3]);
+    } else {
+        const u32x2 w = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(static_cast<const char *>(base) + idx * 2));
+        v[0] = to_f32<ET>(w[0] & 0xffffu); v[1] = to_f32<ET>(w[0] >> 16);
+        v[2] = to_f32<ET>(w[1] & 0xffffu); v[3] = to_f32<ET>(w[1] >> 16);
+    }
+}
+template <class ET, bool F32, bool NT> BP_DEV void store4s(void *base, int64_t idx, const float (&v)[4]) {
+    if constexpr (!NT) {
+        store4<ET, F32>(base, idx, v);
+    } else if constexpr (F32) {
+        u32x4 w = {as_u32(v[0]), as_u32(v[1]), as_u32(v[2]), as_u32(v[3])};
+        __builtin_nontemporal_store(w, reinterpret_cast<u32x4 *>(static_cast<char *>(base) + idx * 4));
+    } else {
+        u32x2 w = {Elem<ET>::pack2(v[0], v[1]), Elem<ET>::pack2(v[2], v[3])};
+        __builtin_nontemporal_store(w, reinterpret_cast<u32x2 *>(static_cast<char *>(base) + idx * 2));
+    }
+}
+
 // RES_F32: dtype of the residual stream (x1 in, x_out) is fp32, else ET.  W_F32: gamma/beta are fp32.
-template <class ET, int CH, bool RES_F32, bool W_F32>
+// NTL / NTS: non-temporal loads / stores of the row data
+template <class ET, int CH, bool RES_F32, bool W_F32, bool NTL = false, bool NTS = false>
 __global__ __launch_bounds__(256) void add_layer_norm_kernel(const LnParams p) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -74,8 +102,8 @@ __global__ __launch_bounds__(256) void add_layer_norm_kernel(const LnParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) x[c][i] = 0.f;
         if (col < p.cols) {
-            if (p.x0_f32) load4<ET, true>(p.x0, base + col, x[c]);
-            else load4<ET, false>(p.x0, base + col, x[c]);
+            if (p.x0_f32) load4s<ET, true, NTL>(p.x0, base + col, x[c]);
+            else load4s<ET, false, NTL>(p.x0, base + col, x[c]);
             if (drop) {
                 uint32_t lo, hi, m = 0u;
                 dropout_bits4(rng, (uint32_t)row, (uint32_t)(col >> 2), lo, hi);
@@ -89,14 +117,14 @@ __global__ __launch_bounds__(256) void add_layer_norm_kernel(const LnParams p) {
             }
             if (p.x1 != nullptr) {
                 float r[4];
-                load4<ET, RES_F32>(p.x1, base + col, r);
+                load4s<ET, RES_F32, NTL>(p.x1, base + col, r);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) x[c][i] += r[i];
             }
             if (p.x_out != nullptr) {
                 // stored in the residual dtype; z below is computed from the UNROUNDED fp32 sum, exactly as
                 // the reference does (ln_fwd_kernels.cuh:131-133: x.data = x_ij; xf[...] = x_ij)
-                store4<ET, RES_F32>(p.x_out, base + col, x[c]);
+                store4s<ET, RES_F32, NTS>(p.x_out, base + col, x[c]);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) sum += x[c][i];
@@ -126,8 +154,8 @@ __global__ __launch_bounds__(256) void add_layer_norm_kernel(const LnParams p) {
             load4<ET, W_F32>(p.beta, col, b);
 #pragma unroll
             for (int i = 0; i < 4; ++i) z[i] = (x[c][i] - mu) * rs * g[i] + b[i];
-            if (p.x0_f32) store4<ET, true>(p.z, base + col, z);
-            else store4<ET, false>(p.z, base + col, z);
+            if (p.x0_f32) store4s<ET, true, NTS>(p.z, base + col, z);
+            else store4s<ET, false, NTS>(p.z, base + col, z);
         }
     }
 }
@@ -136,8 +164,12 @@ template <class ET, bool RES_F32, bool W_F32>
 static hipError_t launch_flags(const LnParams &p, hipStream_t stream) {
     const int ch = (p.cols + 255) / 256;
     dim3 g((unsigned)((p.rows + 3) / 4)), t(256);
+#ifndef BP_LN_NT
+#define BP_LN_NT 0
+#endif
+    constexpr bool NTL = BP_LN_NT == 2 || BP_LN_NT == 3, NTS = BP_LN_NT == 1 || BP_LN_NT == 2;
 #define BP_LN_CASE(N) \
-    if (ch <= N) { hipLaunchKernelGGL((add_layer_norm_kernel<ET, N, RES_F32, W_F32>), g, t, 0, stream, p); return hipGetLastError(); }
+    if (ch <= N) { hipLaunchKernelGGL((add_layer_norm_kernel<ET, N, RES_F32, W_F32, NTL, NTS>), g, t, 0, stream, p); return hipGetLastError(); }
     BP_LN_CASE(1) BP_LN_CASE(2) BP_LN_CASE(3) BP_LN_CASE(4) BP_LN_CASE(6) BP_LN_CASE(8)
     BP_LN_CASE(12) BP_LN_CASE(16) BP_LN_CASE(24) BP_LN_CASE(32)
 #undef BP_LN_CASE

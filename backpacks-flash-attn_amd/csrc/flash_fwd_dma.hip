@@ -63,9 +63,16 @@ __device__ unsigned long long g_fwd_prof[8192][4][12];
 #define FWD_ADD(k, expr) do { } while (0)
 #endif
 
+// BP_FWD_NWAVE = 8 (round-4 experiment, asked for by the round-3 review): a 512-thread workgroup covers 256 queries,
+// i.e. every K / V tile is fetched once per 256 queries instead of once per 128 (half the DMA instructions and barriers per
+// query); shapes whose tiles have fewer than eight 1-KiB pieces keep four waves.
+#ifndef BP_FWD_NWAVE
+#define BP_FWD_NWAVE 4
+#endif
 template <int KD, int NV, bool HAS_V>
 struct FlashDmaCfg {
-    static constexpr int BM = 128, BN = 64, NT = 256, NWAVE = 4, NSTAGE = 2;
+    static constexpr int NWAVE = (BP_FWD_NWAVE == 8 && KD <= 4 && KD >= 3 && (!HAS_V || NV >= 2)) ? 8 : 4;
+    static constexpr int BM = 32 * NWAVE, BN = 64, NT = 64 * NWAVE, NSTAGE = 2;
     static constexpr int KROW = KD <= 4 ? 128 : 256;
     static constexpr int KSLOTS = KROW / 16;
     static constexpr int VROW = NV * 64;
@@ -647,15 +654,19 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
 // (sample, head), the heaviest remaining and the lightest (t and n-1-t): every workgroup then carries the same
 // n+1 key blocks, nothing waits, and both tiles still belong to one group, i.e. one XCD's L2 holds their K/V.
 template <class ET, int KD, int NV, bool HAS_V, bool FULLD, bool DROP>
-__global__ __launch_bounds__(256, BP_FLASH_MINWAVES(NV)) void flash_fwd_dma_kernel(const FlashParams p) {
+__global__ __launch_bounds__((FlashDmaCfg<KD, NV, HAS_V>::NT),
+                             (FlashDmaCfg<KD, NV, HAS_V>::NWAVE == 8 ? 4 : BP_FLASH_MINWAVES(NV)))
+void flash_fwd_dma_kernel(const FlashParams p) {
     using C = FlashDmaCfg<KD, NV, HAS_V>;
     __shared__ __attribute__((aligned(16))) char smem[C::NSTAGE * C::STAGE];
     const uint32_t lds0 = lds_base_addr(smem);
-    const int per_group = p.pair ? (p.n_qtiles + 1) / 2 : p.n_qtiles;
+    const int n_qtiles = (p.max_sq + C::BM - 1) / C::BM;   // (the host's p.n_qtiles counts 128-query tiles)
+    const bool pair = p.pair && n_qtiles > 1;
+    const int per_group = pair ? (n_qtiles + 1) / 2 : n_qtiles;
     int bh, slot;
     if (!xcd_map(blockIdx.x, p.b * p.h, per_group, bh, slot)) return;
-    const int heavy = p.n_qtiles - 1 - slot;
-    const int npass = (p.pair && slot != heavy) ? 2 : 1;
+    const int heavy = n_qtiles - 1 - slot;
+    const int npass = (pair && slot != heavy) ? 2 : 1;
     for (int pass = 0; pass < npass; ++pass) {
         if (pass) __syncthreads();   // every wave is done with the ring before the next tile's DMA refills it
         flash_fwd_tile<ET, KD, NV, HAS_V, FULLD, DROP>(p, smem, lds0, bh, pass ? slot : heavy);
@@ -664,8 +675,10 @@ __global__ __launch_bounds__(256, BP_FLASH_MINWAVES(NV)) void flash_fwd_dma_kern
 
 template <class ET, int KD, int NV, bool HAS_V, bool FULLD, bool DROP>
 static hipError_t launch_one(const FlashParams &p, hipStream_t stream) {
-    const int grid = xcd_grid(p.b * p.h, p.pair ? (p.n_qtiles + 1) / 2 : p.n_qtiles);
-    hipLaunchKernelGGL((flash_fwd_dma_kernel<ET, KD, NV, HAS_V, FULLD, DROP>), dim3(grid), dim3(256), 0, stream, p);
+    using C = FlashDmaCfg<KD, NV, HAS_V>;
+    const int n_qtiles = (p.max_sq + C::BM - 1) / C::BM;
+    const int grid = xcd_grid(p.b * p.h, (p.pair && n_qtiles > 1) ? (n_qtiles + 1) / 2 : n_qtiles);
+    hipLaunchKernelGGL((flash_fwd_dma_kernel<ET, KD, NV, HAS_V, FULLD, DROP>), dim3(grid), dim3(C::NT), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -4,7 +4,8 @@ flash_attn/flash_attn_interface.py (public functions :242-380), with `flash_attn
 `flash_attn_cuda.bwd` (:38-43) by bp_hip.flash_bwd (bp_flash_bwd).
 
 The HIP backward covers the same head dims as the forward fast path (% 8 == 0, <= 128); for anything
-else the autograd Functions fall back to differentiating an eager recomputation (dropout_p = 0 only).
+else the autograd Functions RAISE in backward unless the caller opted in to differentiating an eager recomputation
+(`with bp_hip.allow_eager_fallback():`, dropout_p = 0 only).
 Attention dropout runs inside the kernels (bp_flash_fwd_dropout / bp_flash_bwd_dropout): the forward draws a
 two-word generator state on the device from torch's CUDA generator and saves it for backward, where the
 reference saves and restores the whole CUDA RNG state around its kernel (:56-57,:74-81).
@@ -103,6 +104,11 @@ class _FlashAttnFuncBase(torch.autograd.Function):
                                         rng_state=ctx.rng_state)
         if ctx.dropout_p > 0.0:
             raise RuntimeError('flash_attn (gfx950 build): attention dropout needs head_dim % 8 == 0 and <= 128')
+        if not bp_hip.eager_fallback_allowed():
+            raise RuntimeError(
+                'flash_attn (gfx950 build): the HIP backward takes head_dim %% 8 == 0 and <= 128 (got %d); differentiating '
+                'an eager recomputation instead is opt-in: `with bp_hip.allow_eager_fallback():` around backward()'
+                % q.shape[-1])
         with torch.enable_grad():
             q_, k_, v_ = (t.detach().requires_grad_() for t in (q, k, v))
             out = _eager_varlen(q_, k_, v_, cu_q, cu_k, ctx.softmax_scale, ctx.causal, ctx.max_q, ctx.max_k)

@@ -288,8 +288,21 @@ class BackpackLMHeadModel(BackpackPreTrainedModel, GenerationMixin):
         # tied with the word embeddings of both the trunk and the content model (reference :339-340)
         self.lm_head.weight = self.transformer.embeddings.word_embeddings.weight
 
-    def forward(self, input_ids, position_ids=None, inference_params=None):
+    def forward(self, input_ids, position_ids=None, inference_params=None, logits_out=None):
+        """`logits_out` (not in the reference's signature, :342-351): a caller-owned (B, S, vocab) buffer the LM head
+        writes into -- inference at HBM-filling batches, where the logits are most of the memory (103 MB per sample at
+        Small / S = 1024) and a fresh allocation per step is what the caching allocator cannot re-place."""
         hidden_states = self.transformer(input_ids, position_ids=position_ids,
                                          inference_params=inference_params)
         CausalLMOutput = namedtuple('CausalLMOutput', ['logits'])
-        return CausalLMOutput(logits=self.lm_head(hidden_states))
+        if logits_out is None:
+            return CausalLMOutput(logits=self.lm_head(hidden_states))
+        if torch.is_grad_enabled() and (hidden_states.requires_grad or self.lm_head.weight.requires_grad):
+            raise RuntimeError('logits_out is an inference-only argument (run under torch.no_grad())')
+        want = hidden_states.shape[:-1] + (self.lm_head.weight.shape[0],)
+        if tuple(logits_out.shape) != tuple(want) or logits_out.dtype != hidden_states.dtype \
+                or not logits_out.is_contiguous():
+            raise RuntimeError(f'logits_out must be a contiguous {tuple(want)} tensor of {hidden_states.dtype}')
+        torch.mm(hidden_states.reshape(-1, hidden_states.shape[-1]), self.lm_head.weight.t(),
+                 out=logits_out.view(-1, want[-1]))
+        return CausalLMOutput(logits=logits_out)

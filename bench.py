@@ -127,52 +127,75 @@ def algorithmic_work(cfg, batch, seq):
     }
 
 
-def pick_batch(model, make_ids, candidates, seq, device, steps=3):
+class LogitsBuffer:
+    """ONE persistent (max batch, S, vocab) block the LM head writes into (`logits_out=`): at the HBM-filling batch the
+    logits are most of the memory (Small, S = 1024: 103 MB per sample), and a fresh 100-200 GiB allocation per step is
+    what the caching allocator failed to re-place in round 3 (r03_n / r03_s).  Smaller batches use a leading slice."""
+
+    def __init__(self, vocab, seq, dtype, device):
+        self.vocab, self.seq, self.dtype, self.device = vocab, seq, dtype, device
+        self.buf = None
+
+    def bytes_per_sample(self):
+        return self.seq * self.vocab * torch.empty((), dtype=self.dtype).element_size()
+
+    def get(self, batch):
+        if self.buf is None or self.buf.shape[0] < batch:
+            self.buf = None
+            torch.cuda.empty_cache()
+            self.buf = torch.empty((batch, self.seq, self.vocab), dtype=self.dtype, device=self.device)
+        return self.buf[:batch]
+
+
+def pick_batch(model, make_ids, candidates, seq, device, logits, steps=3, hbm_limit=0.90):
     """Untimed-region batch sweep ("B swept ... to the max that fits"): tokens/s of `steps`
-    forwards at each candidate batch after 2 warm-up forwards.  A candidate whose footprint, extrapolated from the
-    previous one's peak, would pass 85 % of HBM is not attempted; one that still runs out is recorded as such.
-    The sweep goes as far as HBM allows (Small, S = 1024: 103 MB of logits per sample; 2304 samples = 225 GB = 78 %);
-    the LARGEST batch within 1 % of the best rate wins, among those the timed run can hold robustly (see below): the
-    curve is flat once the GEMMs are at their rate.  Returns (batch, the sweep table)."""
+    forwards at each candidate batch after 2 warm-up forwards, logits written into the persistent block.  The first
+    (smallest) candidate measures the footprint per sample besides the logits; the block is then allocated ONCE for the
+    largest candidate whose estimated peak stays under `hbm_limit` of HBM, and every candidate up to it runs.  The
+    LARGEST batch within 1 % of the best rate wins (the curve is flat once the GEMMs are at their rate, so this is the
+    HBM-filling batch).  Returns (batch, the sweep table)."""
     table = []
     total_mem = torch.cuda.get_device_properties(device).total_memory
-    per_sample = None
+    candidates = sorted(candidates)
+    per_sample_other, fixed = None, torch.cuda.memory_allocated(device)
+    largest = candidates[0]
     for b in candidates:
-        if per_sample is not None and per_sample * b > 0.85 * total_mem:
+        if per_sample_other is not None and b > largest:
+            est = fixed + (per_sample_other + logits.bytes_per_sample()) * b
             table.append(dict(batch=b, ms_per_step=None, tokens_per_s=0.0, peak_mem_gb=None,
-                              note=f'skipped: ~{per_sample * b / 2**30:.0f} GB estimated'))
+                              note=f'skipped: ~{est / 2**30:.0f} GiB estimated'))
             continue
         try:
+            out = logits.get(b if per_sample_other is None else largest)[:b]
             torch.cuda.reset_peak_memory_stats(device)
             ids = make_ids(b)
             with torch.no_grad():
                 for _ in range(2):
-                    model(ids).logits
+                    model(ids, logits_out=out)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(steps):
-                    model(ids).logits
+                    model(ids, logits_out=out)
                 torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / steps
             peak = torch.cuda.max_memory_allocated(device)
-            per_sample = peak / b
+            if per_sample_other is None:
+                per_sample_other = max(peak - fixed - logits.bytes_per_sample() * b, 0) / b
+                fit = [c for c in candidates
+                       if fixed + (per_sample_other + logits.bytes_per_sample()) * c <= hbm_limit * total_mem]
+                largest = max(fit) if fit else b
             table.append(dict(batch=b, ms_per_step=round(dt * 1e3, 3), tokens_per_s=round(b * seq / dt, 1),
-                              peak_mem_gb=round(peak / 2**30, 1)))
+                              peak_mem_gb=round(peak / 2**30, 1),
+                              hbm_frac=round(peak / total_mem, 3)))
         except torch.OutOfMemoryError:
             table.append(dict(batch=b, ms_per_step=None, tokens_per_s=0.0, peak_mem_gb=None, note='out of HBM'))
         finally:
-            ids = None
-            torch.cuda.empty_cache()
-    best = max(r['tokens_per_s'] for r in table)
-    if not best:
+            ids = out = None
+    ran = [r for r in table if r['tokens_per_s']]
+    if not ran:
         raise SystemExit('no candidate batch fits in HBM')
-    # ... among the candidates whose footprint stays under 55 % of HBM: above that, the timed run (which keeps the
-    # allocator's cache from step to step) failed to place the next step's logits block although the same batch had run
-    # in this sweep -- 2560 in r03_n, 2304 in r03_s: best-fit splitting of the cached 221 GiB block for a 3.6 GiB request
-    # pins it; `max_split_size_mb` avoids that but re-mallocs the block every step (12x slower, r03_t).  The sweep table
-    # still shows the plateau up to 78 % of HBM.
-    pick = max(r['batch'] for r in table if r['tokens_per_s'] >= 0.99 * best
-               and (r['peak_mem_gb'] or 0) * 2**30 <= 0.55 * total_mem)
+    best = max(r['tokens_per_s'] for r in ran)
+    pick = max(r['batch'] for r in ran if r['tokens_per_s'] >= 0.99 * best)
     return pick, table
 
 
@@ -276,21 +299,21 @@ def main():
                              generator=torch.Generator(device=device).manual_seed(1234 + rank))
 
     sweep = None
+    logits = LogitsBuffer(cfg.vocab_size, seq, dtype, device)
+    cands = []
     if args.batch == 'auto':
         cands = ([int(c) for c in args.batch_candidates.split(',')] if args.batch_candidates
-                 else [default_batch * m for m in (1, 2, 4, 8, 16, 24, 32, 36, 40)])
-        batch, sweep = pick_batch(model, make_ids, cands, seq, device)
-        import gc
-        gc.collect()
+                 else [default_batch * m for m in (1, 2, 4, 8, 16, 24, 26, 28, 30, 32)])
+        batch, sweep = pick_batch(model, make_ids, cands, seq, device, logits)
         torch.cuda.synchronize()
-        torch.cuda.empty_cache()      # the timed run needs the sweep's largest blocks back in one piece
-        if dist is not None:    # every rank runs the batch rank 0 picked
+        if dist is not None:    # every rank runs the SMALLEST batch any rank picked (identical GPUs pick alike)
             t = torch.tensor([batch], device=device)
-            dist.broadcast(t, 0)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
             batch = int(t.item())
     else:
         batch = int(args.batch)
     ids = make_ids(batch)
+    logits_out = logits.get(batch)[:batch]
 
     clock = KernelClock()
     if not args.no_kernel_events and not args.graph:
@@ -298,7 +321,7 @@ def main():
 
     def eager_step():
         with torch.no_grad():
-            return model(ids).logits
+            return model(ids, logits_out=logits_out).logits
 
     step = eager_step
     if args.graph:
@@ -317,30 +340,35 @@ def main():
             graph.replay()
             return graph_out
 
-    # Warm-up.  At the HBM-filling batch the logits tensor alone is most of the memory (2304 samples: 221 GiB) and the
-    # caching allocator may fail to find it a contiguous block in a later iteration although the same batch ran in the
-    # sweep (r03_n / r03_s); every rank then steps down to the next smaller candidate -- the same way on every rank, the
-    # sizes are identical -- instead of failing the run.
+    # Warm-up.  The logits live in the persistent block, so the step allocates only transient activations; should a
+    # rank still run out of HBM, ALL ranks step down together to the next smaller candidate (a MIN all-reduce of a flag
+    # per attempt: ranks must never time different batches).
     out = None
     while True:
+        failed = 0
         try:
             for _ in range(args.warmup):
-                out = None      # never two logits tensors alive
                 out = step()
-            break
         except torch.OutOfMemoryError:
-            out = None
-            smaller = [c for c in (cands if sweep else []) if c < batch]
-            if args.graph or not smaller:
-                raise
-            batch = max(smaller)
+            failed = 1
+        if dist is not None:
+            t = torch.tensor([failed], device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            failed = int(t.item())
+        if not failed:
+            break
+        out = None
+        smaller = [c for c in cands if c < batch]
+        if args.graph or not smaller:
+            raise SystemExit(f'out of HBM at batch {batch} and no smaller candidate to fall back to')
+        batch = max(smaller)
+        if sweep is not None:
             sweep.append(dict(batch=batch, note='timed run fell back to this batch: out of HBM at the picked one'))
-            ids = None
-            import gc
-            gc.collect()
-            torch.cuda.synchronize()
-            torch.cuda.empty_cache()
-            ids = make_ids(batch)
+        ids = None
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        ids = make_ids(batch)
+        logits_out = logits.get(batch)[:batch]
     out = None
     torch.cuda.synchronize()
     if dist is not None:
@@ -349,7 +377,6 @@ def main():
     clock.enabled = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = None
         out = step()
     torch.cuda.synchronize()
     if dist is not None:
@@ -400,7 +427,8 @@ def main():
                                    f'{cfg.n_head} heads, {cfg.n_layer} layers, k={cfg.num_content_vectors} '
                                    f'senses, vocab {cfg.vocab_size}, seq {seq}',
                        'batch_per_gpu': batch, 'global_batch': batch * world, 'seq_len': seq,
-                       'batch_choice': 'auto: largest batch within 1 % of the best rate in batch_sweep whose footprint stays under 55 % of HBM' if sweep else 'given',
+                       'batch_choice': 'auto: largest batch within 1 % of the best rate in batch_sweep (candidates up to 90 % of HBM; logits in one persistent block)' if sweep else 'given',
+                       'hbm_frac_peak': round(torch.cuda.max_memory_allocated(device) / torch.cuda.get_device_properties(device).total_memory, 3),
                        'parallelism': f'{world} independent batch replicas (no data-path collective)'},
         }
         if kernel_rows:

@@ -109,6 +109,14 @@ def main():
         res.append(dict(kernel='sense_dqk(slab gemm + dq + dk)', ms=ms,
                         tflops=(2 * pairs * d * K + 8 * pairs * d) * B / ms / 1e9,
                         gbps=(4 + 2 + 2 * K + 4) * S * d * B / ms / 1e6))
+    if 'ln' in which:
+        rows, cols = B * S, d
+        x0 = torch.randn(rows, cols, device=dev).to(dt)
+        x1 = torch.randn(rows, cols, device=dev)
+        w, bias = torch.ones(cols, device=dev).to(dt), torch.zeros(cols, device=dev).to(dt)
+        ms = timeit(lambda: bp_hip.add_layer_norm(x0, x1, w, bias, 1e-5), a.iters)
+        # reads x0 (2) + residual (4), writes z (2) + residual (4) bytes per element: the trunk's per-block call
+        res.append(dict(kernel='add_layer_norm', rows=rows, ms=ms, tflops=0.0, gbps=rows * cols * 12 / ms / 1e6))
     if 'lnbwd' in which:
         rows, cols = B * S, d
         x = torch.randn(rows, cols, device=dev)

@@ -192,21 +192,30 @@ def test_autograd_functions_use_backward(packing, d):
     eager = _oracle_grads(qkv16[:, :, 0], qkv16[:, :, 1], qkv16[:, :, 2], dout, True, scale, upcast=False)
     cu = torch.arange(0, (b + 1) * s, s, dtype=torch.int32, device=DEV)
     flat = qkv16.reshape(b * s, 3, h, d).to(DEV)
+    g = dout.reshape(b * s, h, d).to(DEV)
+
+    def backward(out):
+        if d % 8 == 0:
+            out.backward(g)
+            return
+        # no HIP backward for this head dim: loud by default, the eager recomputation only on request
+        with pytest.raises(RuntimeError, match='allow_eager_fallback'):
+            out.backward(g, retain_graph=True)
+        with _bp().allow_eager_fallback():
+            out.backward(g)
+
     if packing == 'qkv':
         x = flat.clone().requires_grad_()
-        out = F.flash_attn_unpadded_qkvpacked_func(x, cu, s, 0.0, causal=True)
-        out.backward(dout.reshape(b * s, h, d).to(DEV))
+        backward(F.flash_attn_unpadded_qkvpacked_func(x, cu, s, 0.0, causal=True))
         got = [x.grad[:, i] for i in range(3)]
     elif packing == 'kv':
         q = flat[:, 0].clone().requires_grad_()
         kv = flat[:, 1:].clone().requires_grad_()
-        out = F.flash_attn_unpadded_kvpacked_func(q, kv, cu, cu, s, s, 0.0, causal=True)
-        out.backward(dout.reshape(b * s, h, d).to(DEV))
+        backward(F.flash_attn_unpadded_kvpacked_func(q, kv, cu, cu, s, s, 0.0, causal=True))
         got = [q.grad, kv.grad[:, 0], kv.grad[:, 1]]
     else:
         q, k, v = (flat[:, i].clone().requires_grad_() for i in range(3))
-        out = F.flash_attn_unpadded_func(q, k, v, cu, cu, s, s, 0.0, causal=True)
-        out.backward(dout.reshape(b * s, h, d).to(DEV))
+        backward(F.flash_attn_unpadded_func(q, k, v, cu, cu, s, s, 0.0, causal=True))
         got = [q.grad, k.grad, v.grad]
     got = [g.reshape(b, s, h, d) for g in got]
     _check(got, ref, eager, f'autograd {packing} d={d}')
@@ -242,6 +251,12 @@ def _mix_grads(qk, c_st, dout, w, fused):
     c_st = c_st.clone().requires_grad_()
     if fused:
         out = _bp().sense_mix_autograd(qk, c_st, None, key_weight=w)
+        if w is not None or qk.shape[-1] % 8 or c_st.shape[-1] % 8:
+            # shapes the fused backward kernels do not take: loud by default, the alpha-rebuilding route on request
+            with pytest.raises(RuntimeError, match='allow_eager_fallback'):
+                torch.autograd.grad(out, (qk, c_st), dout.to(out.dtype), retain_graph=True)
+            with _bp().allow_eager_fallback():
+                return torch.autograd.grad(out, (qk, c_st), dout.to(out.dtype))
     else:
         alpha = R.sense_alpha_from_qk(qk)
         c = c_st.transpose(1, 2)

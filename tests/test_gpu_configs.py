@@ -72,6 +72,41 @@ def test_small_config2_whole_model_seq1024():
         assert err <= 3 * b + 1e-3, (name, err, b)
 
 
+def test_small_config5_whole_model_seq4096_fp16():
+    """BASELINE config 5 as a whole model (round-3 review: only the two kernels were checked at S = 4096): Backpack-Small,
+    B = 1, S = 4096, fp16, HIP path against the fp32 CPU oracle of the reference's eager forward
+    (training/src/models/backpack.py:297-314) on the final hidden states and 256 logit rows; the reference's model-test
+    criterion, err <= 3 x the error of the eager fp16 twin on the GPU."""
+    seq = 4096
+    ocfg = R.make_config('small', n_positions=seq, vocab_size=50264)
+    sd = R.init_state_dict(ocfg, seed=0)
+    with torch.no_grad():
+        sd['transformer.contextualization_attn.Wqkv.weight'].mul_(8.0)
+        for i in range(ocfg['n_layer']):
+            sd[f'transformer.gpt2_model.layers.{i}.mixer.Wqkv.weight'].mul_(6.0)
+        sd = {k: v.half().float() for k, v in sd.items()}           # fp16-exact weights for all three runs
+    sd['lm_head.weight'] = sd['transformer.gpt2_model.embeddings.word_embeddings.weight']
+    ids = torch.randint(0, 50257, (1, seq), generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        want = R.backpack_forward(sd, ocfg, ids, return_stages=True)
+    hip = _model_from_sd_keys(sd, ocfg, torch.float16, True, True)
+    eager = _model_from_sd_keys(sd, ocfg, torch.float16, False, False)
+    with torch.no_grad():
+        hid_hip = hip.transformer(ids.to(DEV))
+        hid_eager = eager.transformer(ids.to(DEV))
+        rows = torch.randint(0, seq, (256,), generator=torch.Generator().manual_seed(1))
+        rows[:4] = torch.tensor([0, 1, seq - 2, seq - 1])             # both ends of the causal triangle
+        log_hip = hip.lm_head(hid_hip.flatten(0, 1)[rows.to(DEV)])
+        log_eager = eager.lm_head(hid_eager.flatten(0, 1)[rows.to(DEV)])
+    for got, base, ref, name in ((hid_hip, hid_eager, want['hidden'], 'hidden'),
+                                 (log_hip, log_eager, want['logits'].flatten(0, 1)[rows], 'logits')):
+        err = (got.float().cpu() - ref).abs().max().item()
+        b = (base.float().cpu() - ref).abs().max().item()
+        print(f'small S=4096 fp16 {name}: hip {err:.3e} eager-fp16 {b:.3e} (|ref| max {ref.abs().max().item():.2f})')
+        assert torch.isfinite(got.float()).all()
+        assert err <= 3 * b + 1e-3, (name, err, b)
+
+
 def test_mini_k64_config4_sense_kernels_seq1024():
     """BASELINE config 4 at its real sequence length: k = 64 senses of d_k = 10 (zero-padded to 16 by
     ContextSelfAttn.project), d = 640, S = 1024.  LSE, alpha (row sums, exact zeros above the diagonal, a row

@@ -162,3 +162,49 @@ def test_raw_abi_mix_with_and_without_queue_ws():
             assert rc == 0
         torch.cuda.synchronize()
         assert torch.equal(out, want)
+
+
+def test_null_queue_ws_is_refused_under_graph_capture():
+    """C ABI 4: a persistent launch with queue_ws == NULL on a stream that is being captured returns BP_ERR_QUEUE_WS (-8)
+    instead of capturing a graph that would replay on the library's shared record (round-3 review); with a caller-owned
+    record the same capture succeeds and replays to the eager result.  Covers bp_sense_mix and bp_sense_mix_dc."""
+    import ctypes
+    bp = _bp()
+    torch.manual_seed(10)
+    b, s, k, dk, d = 1, 256, 4, 16, 256
+    qk = torch.randn(b, s, 2, k, dk, device=DEV).bfloat16()
+    c = torch.randn(b, s, k, d, device=DEV).bfloat16()
+    dout = torch.randn(b, s, d, device=DEV).bfloat16()
+    lse = bp.sense_lse(qk)
+    want = bp.sense_mix(qk, c, lse=lse)
+    want_dc = bp.sense_mix_dc(qk, dout, lse, dk ** -0.5, c)
+    out = torch.zeros(b, s, d, device=DEV, dtype=torch.bfloat16)
+    dc = torch.zeros_like(c)
+    queue = torch.empty(16, dtype=torch.int32, device=DEV)
+    queue2 = torch.empty(16, dtype=torch.int32, device=DEV)
+
+    def mix(q):
+        return bp.lib().bp_sense_mix(qk.data_ptr(), c.data_ptr(), out.data_ptr(), lse.data_ptr(), 1, b, s, k, dk, d,
+                                     qk.stride(0), qk.stride(1), qk.stride(2), qk.stride(3), c.stride(0), c.stride(1),
+                                     c.stride(2), out.stride(0), out.stride(1), dk ** -0.5, 1, q,
+                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    def mix_dc(q):
+        return bp.lib().bp_sense_mix_dc(qk.data_ptr(), dout.data_ptr(), lse.data_ptr(), dc.data_ptr(), b, s, k, dk, d,
+                                        qk.stride(0), qk.stride(1), qk.stride(2), qk.stride(3), dout.stride(0),
+                                        dout.stride(1), dc.stride(0), dc.stride(1), dc.stride(2), dk ** -0.5, 1, q,
+                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    assert mix(None) == 0 and mix_dc(None) == 0          # eager launches may use the library's ring
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    codes = []
+    with torch.cuda.graph(graph):
+        codes += [mix(None), mix_dc(None)]                # refused: nothing is captured for these two
+        codes += [mix(queue.data_ptr()), mix_dc(queue2.data_ptr())]
+    assert codes == [-8, -8, 0, 0], codes
+    assert b'queue_ws' in bp.lib().bp_strerror(-8)
+    out.zero_(); dc.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want) and torch.equal(dc, want_dc)

@@ -57,3 +57,12 @@ def test_train_step_two_ranks():
                        'gloo'], 29544)
     assert line['n_gpus'] == 2 and line['value'] > 0 and line['launch'].endswith('gloo')
     assert line['grad_allreduce_bytes'] > 680e6 and 5 < line['loss'] < 13
+    # what an N-GPU run needs to be conclusive: the collective timed on its own, as bus bandwidth, next to both bounds
+    assert line['allreduce_ms'] > 0 and line['bus_gbps'] > 0 and line['ms_per_step_no_sync'] > 0
+    assert abs(line['bound_ring_ms'] - 2 * 0.5 * line['grad_allreduce_bytes'] / 153e9 * 1e3) < 1e-2
+    assert abs(line['bound_all_links_ms'] - line['bound_ring_ms']) < 1e-6      # N = 2: one peer, one link
+    # the reference's gradient-compression hook (fp16 on the wire: half the bytes), same loss
+    half = _torchrun2(['scripts/bench_train_step.py', '--batch', '1', '--steps', '1', '--warmup', '1', '--dist-backend',
+                       'gloo', '--grad-compress', 'fp16'], 29545)
+    assert half['grad_compress'] == 'fp16' and half['grad_allreduce_bytes'] * 2 == line['grad_allreduce_bytes']
+    assert abs(half['loss'] - line['loss']) < 0.05

@@ -395,3 +395,21 @@ def test_integration_doc_asserts_the_header_abi_version():
     assert all(v == version for v in asserted), (asserted, version)
     import bp_hip
     assert bp_hip.ABI_VERSION == version
+
+
+def test_lm_head_writes_into_a_caller_owned_logits_buffer():
+    """`logits_out=` (bench.py's persistent logits block): same numbers as the allocating call, written in place;
+    inference only; shape / dtype checked."""
+    torch.manual_seed(0)
+    model = BackpackLMHeadModel(nano_config()).eval()
+    ids = torch.randint(0, 96, (2, 16))
+    with torch.no_grad():
+        want = model(ids).logits
+        buf = torch.full((3, 16, 96), float('nan'))
+        got = model(ids, logits_out=buf[:2]).logits
+    assert got.data_ptr() == buf.data_ptr() and torch.allclose(got, want, atol=1e-6)
+    assert torch.isnan(buf[2]).all()
+    with pytest.raises(RuntimeError, match='inference-only'):
+        model(ids, logits_out=buf[:2])
+    with torch.no_grad(), pytest.raises(RuntimeError, match='logits_out must be'):
+        model(ids, logits_out=torch.empty(2, 16, 95))

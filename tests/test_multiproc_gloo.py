@@ -59,6 +59,20 @@ def _worker(rank, world, port, tmp):
             mine = q.grad.clone()
             dist.all_reduce(mine)
             assert torch.allclose(p.grad, mine / world, atol=1e-6), n
+        # --- the reference's gradient-compression comm hook (training/src/distributed/ddp_comm_hooks.py:9-43): the
+        #     bucket is divided by the world size, cast to 16 bit, summed, copied back -> the fp32 mean to 16-bit precision
+        from src.distributed.ddp_comm_hooks import HOOKS, bf16_compress_hook, fp16_compress_hook
+        assert HOOKS == {'none': None, 'fp16': fp16_compress_hook, 'bf16': bf16_compress_hook}
+        for hook, rel in ((fp16_compress_hook, 2e-3), (bf16_compress_hook, 1.6e-2)):
+            third = BackpackLMHeadModel(cfg)
+            third.load_state_dict(local.state_dict())
+            ddp3 = torch.nn.parallel.DistributedDataParallel(third, find_unused_parameters=False,
+                                                             gradient_as_bucket_view=True)
+            ddp3.register_comm_hook(None, hook)
+            torch.nn.functional.cross_entropy(ddp3(ids).logits.flatten(0, 1), ids.flatten()).backward()
+            for (n, p), (_, q) in zip(model.named_parameters(), third.named_parameters()):
+                assert q.grad.dtype == torch.float32
+                assert (q.grad - p.grad).abs().max() <= rel * p.grad.abs().max() + 1e-7, (hook.__name__, n)
         with open(os.path.join(tmp, f'ok{rank}'), 'w') as f:
             f.write('ok')
     finally:
