@@ -56,7 +56,7 @@ template <class ET, bool F32> BP_DEV void store4(void *base, int64_t idx, const 
 }
 
 // Streaming (non-temporal) forms for the forward's row data: every byte is touched once per launch.  BP_LN_NT selects
-// which accesses carry the hint (development A/B: 0 none, 1 stores, 2 loads and stores, 3 loads); the launcher picks per
+// which accesses carry the hint (development A/B: 0 none, 1 stores, 2 loads and stores, 3 loads, 4 loads + residual store); the launcher picks per
 // call (see launch_flags).
 template <class ET, bool F32, bool NT> BP_DEV void load4s(const void *base, int64_t idx, float (&v)[4]) {
     if constexpr (!NT) {
@@ -83,8 +83,8 @@ template <class ET, bool F32, bool NT> BP_DEV void store4s(void *base, int64_t i
 }
 
 // RES_F32: dtype of the residual stream (x1 in, x_out) is fp32, else ET.  W_F32: gamma/beta are fp32.
-// NTL / NTS: non-temporal loads / stores of the row data
-template <class ET, int CH, bool RES_F32, bool W_F32, bool NTL = false, bool NTS = false>
+// NTL / NTS / NTZ: non-temporal loads of x0 and the residual / store of the residual / store of z
+template <class ET, int CH, bool RES_F32, bool W_F32, bool NTL = false, bool NTS = false, bool NTZ = NTS>
 __global__ __launch_bounds__(256) void add_layer_norm_kernel(const LnParams p) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -154,8 +154,8 @@ __global__ __launch_bounds__(256) void add_layer_norm_kernel(const LnParams p) {
             load4<ET, W_F32>(p.beta, col, b);
 #pragma unroll
             for (int i = 0; i < 4; ++i) z[i] = (x[c][i] - mu) * rs * g[i] + b[i];
-            if (p.x0_f32) store4s<ET, true, NTS>(p.z, base + col, z);
-            else store4s<ET, false, NTS>(p.z, base + col, z);
+            if (p.x0_f32) store4s<ET, true, NTZ>(p.z, base + col, z);
+            else store4s<ET, false, NTZ>(p.z, base + col, z);
         }
     }
 }
@@ -164,12 +164,16 @@ template <class ET, bool RES_F32, bool W_F32>
 static hipError_t launch_flags(const LnParams &p, hipStream_t stream) {
     const int ch = (p.cols + 255) / 256;
     dim3 g((unsigned)((p.rows + 3) / 4)), t(256);
+    // shipped: 4 -- x0 and the incoming residual are read once and never again, the outgoing residual is next read a GEMM
+    // and an attention launch later (long evicted at any batch that matters); z stays cacheable for the GEMM that follows.
+    // r04_d / r04_e on one box each: kernel alone -6.7 % (B = 64) ... -4 % (B = 1536) with nt loads, in the model
+    // 2.397 -> 2.336 ms per launch at B = 1536 (0.756 -> 0.776 of 8 TB/s), step +0.3 %
 #ifndef BP_LN_NT
-#define BP_LN_NT 0
+#define BP_LN_NT 4
 #endif
-    constexpr bool NTL = BP_LN_NT == 2 || BP_LN_NT == 3, NTS = BP_LN_NT == 1 || BP_LN_NT == 2;
+    constexpr bool NTL = BP_LN_NT >= 2, NTS = BP_LN_NT == 1 || BP_LN_NT == 2 || BP_LN_NT == 4, NTZ = BP_LN_NT == 1 || BP_LN_NT == 2;
 #define BP_LN_CASE(N) \
-    if (ch <= N) { hipLaunchKernelGGL((add_layer_norm_kernel<ET, N, RES_F32, W_F32, NTL, NTS>), g, t, 0, stream, p); return hipGetLastError(); }
+    if (ch <= N) { hipLaunchKernelGGL((add_layer_norm_kernel<ET, N, RES_F32, W_F32, NTL, NTS, NTZ>), g, t, 0, stream, p); return hipGetLastError(); }
     BP_LN_CASE(1) BP_LN_CASE(2) BP_LN_CASE(3) BP_LN_CASE(4) BP_LN_CASE(6) BP_LN_CASE(8)
     BP_LN_CASE(12) BP_LN_CASE(16) BP_LN_CASE(24) BP_LN_CASE(32)
 #undef BP_LN_CASE

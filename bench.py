@@ -445,9 +445,25 @@ def main():
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
-                    traffic = tj.get(f"{args.workload}/b{batch}/{dom['kernel']}")
+                    key = f"{args.workload}/b{batch}/{dom['kernel']}"
+                    traffic = tj.get(key)
                     if traffic is not None:
-                        traffic_source = 'quoted from profiles/traffic.json: ' + tj.get('_source', 'rocprofv3 --pmc pass')
+                        traffic_source = ('quoted from profiles/traffic.json (' + tj.get('_files', {}).get(key, '?') + '): '
+                                          + tj.get('_source', 'rocprofv3 --pmc pass'))
+                    else:
+                        # no counter pass at exactly this batch (the auto pick moves between the candidates on the
+                        # plateau): scale the nearest measured batch linearly -- per-sample traffic of these kernels is
+                        # flat from 512 samples up (b512 / b1536 / b1920 / b2048 / b2304 entries of the table)
+                        measured = sorted((abs(int(k.split('/')[1][1:]) - batch), int(k.split('/')[1][1:]), v)
+                                          for k, v in tj.items() if k.startswith(args.workload + '/b')
+                                          and k.endswith('/' + dom['kernel']) and isinstance(v, int))
+                        if measured and batch >= 512 and measured[0][1] >= 512:
+                            _, b_ref, v_ref = measured[0]
+                            ref_key = f"{args.workload}/b{b_ref}/{dom['kernel']}"
+                            traffic = int(v_ref * batch / b_ref)
+                            traffic_source = (f'scaled x{batch}/{b_ref} from the batch-{b_ref} counter pass in profiles/traffic.json ('
+                                              + tj.get('_files', {}).get(ref_key, '?') + '): '
+                                              + tj.get('_source', 'rocprofv3 --pmc pass'))
                 except Exception:
                     traffic = None
             if dom['kernel'] == 'add_layer_norm_kernel':
