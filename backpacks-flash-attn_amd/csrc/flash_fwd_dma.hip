@@ -29,14 +29,6 @@
 #ifndef BP_FWD_STREAM
 #define BP_FWD_STREAM 1
 #endif
-// BP_FWD_WEAVE (round 4): the clean tiles of the trunk kernel (V present, no dropout) run a body in which ONE wave feeds
-// both pipes -- S^T of key half 1 issues between the exponentials of half 0, P V of half 0 between the exponentials of
-// half 1 -- instead of three single-pipe phases (S^T | softmax | P V) that only overlap across waves.  Same registers.
-// Each 32-key half is validated on its own (row sum against the overflow limit); a failing half is redone the textbook
-// way before anything of it was accumulated (retry_half).
-#ifndef BP_FWD_WEAVE
-#define BP_FWD_WEAVE 0
-#endif
 #include "bp_common.h"
 #include "bp_dma.h"
 #include "bp_kernels.h"
@@ -452,108 +444,6 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
     };
 
 
-    // ---- woven clean tile (BP_FWD_WEAVE) ---------------------------------------------------------------------------
-    constexpr bool WEAVE = (BP_FWD_WEAVE != 0) && PACKED_SUM;
-    // exponentials of score pairs [p_begin, p_end) of one 32-key half (pair pr = registers 2 pr, 2 pr + 1 -> word pr & 3 of
-    // K-step pr >> 2), pinned in place between the volatile pins of the MFMAs around them
-    // (order: the group reads the scale through a scalar that an empty volatile asm redefines right behind the MFMA's
-    // pin -- its fmas cannot rise above that MFMA --, its results are pinned, so it cannot sink below the next one;
-    // pinning the SCORES instead made hipcc copy every second one into place: 16 v_mov per tile)
-    auto softmax_pairs = [&](const f32x16 &st, u32x4 (&pk)[2], float &ra, float &rb, int p_begin, int p_end) {
-        float c2g = c2;
-        asm volatile("" : "+s"(c2g));
-#pragma unroll
-        for (int pr = 0; pr < 8; ++pr) {
-            if (pr < p_begin || pr >= p_end) continue;
-            const float x0 = fast_exp2(fmaf(st[2 * pr], c2g, -mc));
-            const float x1 = fast_exp2(fmaf(st[2 * pr + 1], c2g, -mc));
-            uint32_t w = E::pack2(x0, x1);
-            if (pr & 1) { rb = E::add_pair(w, rb); asm volatile("" : "+v"(w), "+v"(rb)); }
-            else { ra = E::add_pair(w, ra); asm volatile("" : "+v"(w), "+v"(ra)); }
-            pk[pr >> 2][pr & 3] = w;
-        }
-    };
-    // V^T operand of P V MFMA m of a half (K-step m / NV, head-dim block m % NV)
-    auto v_operand = [&](const char *vbuf, int kk, int m) {
-        const int rows = (kk * 32 + (m / NV) * 16) * C::VROW;
-        const u32x2 lo = lds_read_tr16_8B(vbuf, v_read_off[m % NV] + rows);
-        const u32x2 hi = lds_read_tr16_8B(vbuf, v_read_off[m % NV] + rows + 8 * C::VROW);
-        return u32x4{lo[0], lo[1], hi[0], hi[1]};
-    };
-    // a half whose fast exponentials overflowed (rare): redo it with the true maximum -- move the reference point, rescale
-    // O and l -- from scores recomputed out of LDS; nothing of this half has been accumulated yet
-    auto retry_half = [&](const char *kbuf, int kk, u32x4 (&pk)[2]) {
-        f32x16 st = scores(kbuf, kk);
-        float mxa = st[0], mxb = st[8];
-#pragma unroll
-        for (int r = 1; r < 8; ++r) { mxa = fmaxf(mxa, st[r]); mxb = fmaxf(mxb, st[8 + r]); }
-        const float m_new = fmaxf(xhalf_max(fmaxf(mxa, mxb)), m_run);
-        const float mc_new = (m_new == -INFINITY) ? 0.f : m_new * c2;
-        const float alpha = fast_exp2(m_run * c2 - mc_new);
-        l_run *= alpha;
-#pragma unroll
-        for (int n = 0; n < (HAS_V ? NV : 1); ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[n][r] *= alpha;
-        m_run = m_new;
-        mc = mc_new;
-        float ra = 0.f, rb = 0.f;
-        softmax_pairs(st, pk, ra, rb, 0, 8);
-        return ra + rb;
-    };
-    auto woven_tile = [&](const char *kbuf, const char *vbuf) {
-        constexpr int NPV = 2 * NV;   // P V MFMAs per 32-key half
-        f32x16 st0, st1, zero;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-        // S^T of key half 0: KD dependent MFMAs, operands two ahead
-        mfma_stream<KD>([&](int i) { return lds_read_16B(kbuf, k_read_off[i]); },
-                        [&](int i, const u32x4 &a) { st0 = E::mfma(a, qf[i], i == 0 ? zero : st0); });
-        // A: S^T of half 1, the exponentials of half 0 between its MFMAs
-        u32x4 p0[2], p1[2];
-        float ra = 0.f, rb = 0.f;
-        {
-            u32x4 a0 = lds_read_16B(kbuf, k_read_off[0] + 32 * C::KROW);
-            u32x4 a1 = lds_read_16B(kbuf, k_read_off[KD > 1 ? 1 : 0] + 32 * C::KROW);
-#pragma unroll
-            for (int i = 0; i < KD; ++i) {
-                u32x4 a2 = a0;
-                if (i + 2 < KD) a2 = lds_read_16B(kbuf, k_read_off[i + 2 < KD ? i + 2 : 0] + 32 * C::KROW);
-                asm volatile("" : "+v"(a0));
-                st1 = E::mfma(a0, qf[i], i == 0 ? zero : st1);
-                asm volatile("" : "+v"(st1));
-                softmax_pairs(st0, p0, ra, rb, 8 * i / KD, 8 * (i + 1) / KD);
-                a0 = a1;
-                a1 = a2;
-            }
-        }
-        float rs = ra + rb;
-        if (__builtin_expect(!__all(rs <= kLimit), 0)) rs = retry_half(kbuf, 0, p0);
-        l_run += rs;
-        // B: P V of half 0, the exponentials of half 1 between its MFMAs
-        ra = 0.f; rb = 0.f;
-        {
-            u32x4 a0 = v_operand(vbuf, 0, 0), a1 = v_operand(vbuf, 0, NPV > 1 ? 1 : 0);
-#pragma unroll
-            for (int m = 0; m < NPV; ++m) {
-                u32x4 a2 = a0;
-                if (m + 2 < NPV) a2 = v_operand(vbuf, 0, m + 2 < NPV ? m + 2 : 0);
-                asm volatile("" : "+v"(a0));
-                acc[m % NV] = E::mfma(a0, p0[m / NV], acc[m % NV]);
-                asm volatile("" : "+v"(acc[m % NV]));
-                softmax_pairs(st1, p1, ra, rb, 8 * m / NPV, 8 * (m + 1) / NPV);
-                a0 = a1;
-                a1 = a2;
-            }
-        }
-        rs = ra + rb;
-        if (__builtin_expect(!__all(rs <= kLimit), 0)) rs = retry_half(kbuf, 1, p1);
-        l_run += rs;
-        // C: P V of half 1
-        mfma_stream<NPV>([&](int m) { return v_operand(vbuf, 1, m); },
-                         [&](int m, const u32x4 &a) { acc[m % NV] = E::mfma(a, p1[m / NV], acc[m % NV]); });
-    };
-
     if (nkb > 0) issue(0);
     // One ring step; SLOT is the ring slot as a compile-time constant (the loop is unrolled by the ring depth), so
     // the LDS addresses of all operand reads fold into instruction offsets.
@@ -576,35 +466,9 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
             tile(kb, kbuf, vbuf, kb == 0 || kb >= my_clean_end);
         }
     };
-    if constexpr (WEAVE) {
-        // Three sequential loops with ONE body each (an if/else join of two bodies inside one loop makes the register
-        // allocator copy or spill the accumulators, DESIGN.md compiler findings): the first tile (exact: it sets the
-        // reference maximum) | an EVEN number of clean tiles in the woven body, so that every ring slot stays a
-        // compile-time constant | the rest (a left-over clean tile, the diagonal, the sequence end) in the exact body.
-        auto begin_step = [&](int kb) {
-            wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            if (kb + 1 < nkb) issue(kb + 1);
-        };
-        if (nkb > 0) ring_step(0, std::integral_constant<int, 0>{});
-        const int fast_end = my_nkb > 0 ? min(my_clean_end, nkb) : 1;
-        const int woven_end = 1 + 2 * ((max(fast_end, 1) - 1) / 2);   // odd: the tail loop starts on slot 1
-        int kb = 1;
-        for (; kb < woven_end; kb += 2) {
-            begin_step(kb);
-            woven_tile(smem + C::STAGE, smem + C::STAGE + C::KTILE);
-            begin_step(kb + 1);
-            woven_tile(smem, smem + C::KTILE);
-        }
-        for (; kb < nkb; kb += 2) {
-            ring_step(kb, std::integral_constant<int, 1>{});
-            if (kb + 1 < nkb) ring_step(kb + 1, std::integral_constant<int, 0>{});
-        }
-    } else {
-        for (int kb = 0; kb < nkb; kb += 2) {
-            ring_step(kb, std::integral_constant<int, 0>{});
-            if (kb + 1 < nkb) ring_step(kb + 1, std::integral_constant<int, 1>{});
-        }
+    for (int kb = 0; kb < nkb; kb += 2) {
+        ring_step(kb, std::integral_constant<int, 0>{});
+        if (kb + 1 < nkb) ring_step(kb + 1, std::integral_constant<int, 1>{});
     }
 
     FWD_TICK(ep0);
@@ -665,6 +529,9 @@ void flash_fwd_dma_kernel(const FlashParams p) {
     const int per_group = pair ? (n_qtiles + 1) / 2 : n_qtiles;
     int bh, slot;
     if (!xcd_map(blockIdx.x, p.b * p.h, per_group, bh, slot)) return;
+    // (round 4, r04_g: the workgroups resident on one CU are XCD-local blocks c, c + 32, c + 64, ... and therefore all carry the
+    // SAME pair of query tiles; rotating the pair index by the residency round and / or running the light tile first in
+    // every other round, so that co-resident workgroups are never in the same phase, changed nothing: +-0.5 %)
     const int heavy = n_qtiles - 1 - slot;
     const int npass = (pair && slot != heavy) ? 2 : 1;
     for (int pass = 0; pass < npass; ++pass) {
