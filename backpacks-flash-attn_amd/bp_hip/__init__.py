@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('BP_HIP_LIB') or os.path.join(_HERE, 'libbackpack_hip.so')  # env: A/B builds only
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 
@@ -64,6 +64,9 @@ SIGNATURES = {
     'bp_add_layer_norm': (_i32, [_ptr] * 6 + [_i64, _i32, _f32] + [_i32] * 4 + [_ptr]),
     'bp_dropout_add_layer_norm': (_i32, [_ptr] * 7 + [_i64, _i32, _f32] + [_i32] * 5 + [_f32, _ptr, _ptr]),
     'bp_dropout_add_layer_norm_bwd': (_i32, [_ptr] * 9 + [_i64, _i32, _f32] + [_i32] * 4 + [_f32, _ptr, _ptr]),
+    'bp_ln_bwd_ws_floats': (_i64, [_i32, _i32]),
+    'bp_dropout_add_layer_norm_scaled': (_i32, [_ptr] * 9 + [_i64, _i32, _f32] + [_i32] * 5 + [_f32, _ptr, _ptr]),
+    'bp_dropout_add_layer_norm_scaled_bwd': (_i32, [_ptr] * 13 + [_i64, _i64, _i32, _f32] + [_i32] * 4 + [_f32, _ptr, _ptr]),
     'bp_softmax_bwd_causal': (_i32, [_ptr, _ptr, _i64, _i32, _f32, _i32, _ptr]),
     'bp_add_layer_norm_bwd': (_i32, [_ptr] * 9 + [_i64, _i32, _f32, _i32, _i32, _i32, _ptr]),
     'bp_xentropy_fwd': (_i32, [_ptr] * 4 + [_i64, _i32, _i64, _f32, _i32, _i32, _ptr]),
@@ -421,8 +424,25 @@ def _ln_16bit_code(*tensors):
     return 1, torch.bfloat16
 
 
+def _ln_scales(x0, weight, rowscale, colscale):
+    """Checked, contiguous (rowscale, colscale) of the fused LayerNorm: rowscale one value per row in x0's dtype,
+    colscale one per column in the weights' dtype (reference: csrc/layer_norm/ln_api.cpp:122-135)."""
+    cols = x0.shape[-1]
+    if rowscale is not None:
+        _require_cuda(rowscale)
+        if rowscale.numel() != x0.numel() // cols or rowscale.dtype != x0.dtype:
+            raise RuntimeError('bp_hip.add_layer_norm: rowscale must hold one value per row, in x0\'s dtype')
+        rowscale = rowscale.contiguous()
+    if colscale is not None:
+        _require_cuda(colscale)
+        if colscale.shape != (cols,) or colscale.dtype != weight.dtype:
+            raise RuntimeError('bp_hip.add_layer_norm: colscale (layerscale) must be (cols,) in the weights\' dtype')
+        colscale = colscale.contiguous()
+    return rowscale, colscale
+
+
 def add_layer_norm(x0, x1, weight, bias, eps, residual_dtype=None, return_residual=True, dropout_p=0.0,
-                   rng_state=None, return_dropout_mask=False):
+                   rng_state=None, return_dropout_mask=False, rowscale=None, colscale=None):
     """Fused z = LayerNorm(dropout(x0) / (1 - p) + x1) (fp32 math) and the updated residual stream
     x = dropout(x0) / (1 - p) + x1.
 
@@ -431,7 +451,9 @@ def add_layer_norm(x0, x1, weight, bias, eps, residual_dtype=None, return_residu
     the uint8 keep mask (all ones without dropout).  residual_dtype defaults to x1's dtype (reference rule,
     csrc/layer_norm/ln_api.cpp:99-102).  Replaces dropout_add_layer_norm (flash_attn/ops/layer_norm.py:207-217).
     dropout_p > 0 draws from `rng_state` (new_rng_state; pass your own to hand the same state to
-    add_layer_norm_bwd)."""
+    add_layer_norm_bwd).  rowscale (one value per row, x0's dtype) / colscale (cols, the weights' dtype): x0 is multiplied
+    by rowscale[row] before and by colscale[col] after the dropout -- DropPath and LayerScale (`rowscale`, `layerscale` of
+    the reference's dropout_add_layer_norm)."""
     _require_cuda(x0, x1, weight, bias)
     if x0.dtype not in (torch.float16, torch.bfloat16, torch.float32):
         raise RuntimeError(f'bp_hip.add_layer_norm: x0 must be fp16, bf16 or fp32, got {x0.dtype}')
@@ -461,14 +483,17 @@ def add_layer_norm(x0, x1, weight, bias, eps, residual_dtype=None, return_residu
                  else torch.ones(x0c.shape, dtype=torch.uint8, device=x0.device))
     rows = x0c.numel() // cols
     wc, bc = weight.contiguous(), bias.contiguous()
+    rowscale, colscale = _ln_scales(x0c, weight, rowscale, colscale)
     with torch.cuda.device(x0.device):
-        code = lib().bp_dropout_add_layer_norm(
+        code = lib().bp_dropout_add_layer_norm_scaled(
             x0c.data_ptr(), x1c.data_ptr() if x1c is not None else None, wc.data_ptr(), bc.data_ptr(),
+            rowscale.data_ptr() if rowscale is not None else None,
+            colscale.data_ptr() if colscale is not None else None,
             z.data_ptr(), xo.data_ptr() if xo is not None else None,
             dmask.data_ptr() if (dmask is not None and dropout_p > 0.0) else None, rows, cols, float(eps), code_dt,
             int(x0_f32), int(x1c is not None and x1c.dtype == torch.float32), int(residual_dtype == torch.float32),
             int(weight.dtype == torch.float32), dropout_p, rng_ptr, _stream())
-    _check(code, 'bp_dropout_add_layer_norm')
+    _check(code, 'bp_dropout_add_layer_norm_scaled')
     outs = (z, xo) if return_residual else (z,)
     if return_dropout_mask:
         outs = outs + (dmask,)
@@ -662,13 +687,15 @@ def add_layer_norm_bwd_supported(x0_dtype, cols):
     return x0_dtype in (torch.float16, torch.bfloat16, torch.float32) and cols % 4 == 0 and cols <= 2048
 
 
-def add_layer_norm_bwd(dz, dx_in, x, weight, eps, want_dx1, dropout_p=0.0, rng_state=None):
-    """Backward of add_layer_norm: (dx0 in dz's dtype, dx1 in x's dtype or None, dweight, dbias).
+def add_layer_norm_bwd(dz, dx_in, x, weight, eps, want_dx1, dropout_p=0.0, rng_state=None, rowscale=None, colscale=None,
+                       x0=None):
+    """Backward of add_layer_norm: (dx0 in dz's dtype, dx1 in x's dtype or None, dweight, dbias[, dcolscale]).
     dz (..., cols) in the forward's x0 / z dtype; dx_in gradient of the residual output (x's dtype) or None; x
     the summed stream the forward normalised (fp32 or dz's dtype).  With dropout, (dropout_p, rng_state) are the
-    forward's: dx0 passes the regenerated mask and the 1 / (1 - p) scale.  Replaces dropout_add_ln_bwd
-    (flash_attn/ops/layer_norm.py:47-76)."""
-    _require_cuda(dz, dx_in, x, weight)
+    forward's: dx0 passes the regenerated mask and the 1 / (1 - p) scale.  rowscale / colscale: the forward's; with a
+    colscale the forward's x0 is needed too and dcolscale is appended.  Replaces dropout_add_ln_bwd
+    (flash_attn/ops/layer_norm.py:27-52)."""
+    _require_cuda(dz, dx_in, x, weight, x0)
     cols = dz.shape[-1]
     dzc, xc = dz.contiguous(), x.contiguous()
     dxc = dx_in.contiguous() if dx_in is not None else None
@@ -677,20 +704,30 @@ def add_layer_norm_bwd(dz, dx_in, x, weight, eps, want_dx1, dropout_p=0.0, rng_s
     if float(dropout_p) > 0.0 and rng_state is None:
         raise RuntimeError('bp_hip.add_layer_norm_bwd: dropout_p > 0 needs the rng_state the forward used')
     dropout_p, rng_state, rng_ptr = _dropout_args(dropout_p, rng_state, dz.device)
+    rowscale, colscale = _ln_scales(dzc, weight, rowscale, colscale)
+    x0c = None
+    if colscale is not None:
+        if x0 is None or x0.shape != dz.shape or x0.dtype != dz.dtype:
+            raise RuntimeError('bp_hip.add_layer_norm_bwd: the gradient of colscale needs the forward\'s x0')
+        x0c = x0.contiguous()
     code_dt, _ = _ln_16bit_code(dzc, xc, weight)
     rows = dzc.numel() // cols
     dx0 = torch.empty_like(dzc)
     dx1 = torch.empty_like(xc) if want_dx1 else None
     dw, db = torch.empty_like(weight), torch.empty_like(weight)
-    ws = torch.empty((2, LN_BWD_WS_ROWS, cols), dtype=torch.float32, device=dz.device)
+    dcs = torch.empty_like(weight) if colscale is not None else None
+    ws = torch.empty(int(lib().bp_ln_bwd_ws_floats(cols, int(colscale is not None))), dtype=torch.float32, device=dz.device)
     with torch.cuda.device(dz.device):
-        code = lib().bp_dropout_add_layer_norm_bwd(
-            dzc.data_ptr(), dxc.data_ptr() if dxc is not None else None, xc.data_ptr(), weight.data_ptr(),
+        code = lib().bp_dropout_add_layer_norm_scaled_bwd(
+            dzc.data_ptr(), dxc.data_ptr() if dxc is not None else None, xc.data_ptr(),
+            x0c.data_ptr() if x0c is not None else None, weight.data_ptr(),
+            rowscale.data_ptr() if rowscale is not None else None, colscale.data_ptr() if colscale is not None else None,
             dx0.data_ptr(), dx1.data_ptr() if dx1 is not None else None, dw.data_ptr(), db.data_ptr(),
-            ws.data_ptr(), rows, cols, float(eps), code_dt, int(dzc.dtype == torch.float32),
-            int(xc.dtype == torch.float32), int(weight.dtype == torch.float32), dropout_p, rng_ptr, _stream())
-    _check(code, 'bp_dropout_add_layer_norm_bwd')
-    return dx0, dx1, dw, db
+            dcs.data_ptr() if dcs is not None else None, ws.data_ptr(), ws.numel(), rows, cols, float(eps), code_dt,
+            int(dzc.dtype == torch.float32), int(xc.dtype == torch.float32), int(weight.dtype == torch.float32),
+            dropout_p, rng_ptr, _stream())
+    _check(code, 'bp_dropout_add_layer_norm_scaled_bwd')
+    return (dx0, dx1, dw, db) if colscale is None else (dx0, dx1, dw, db, dcs)
 
 
 def _xent_dtype(t):

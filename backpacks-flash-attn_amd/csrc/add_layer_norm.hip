@@ -84,7 +84,8 @@ template <class ET, bool F32, bool NT> BP_DEV void store4s(void *base, int64_t i
 
 // RES_F32: dtype of the residual stream (x1 in, x_out) is fp32, else ET.  W_F32: gamma/beta are fp32.
 // NTL / NTS / NTZ: non-temporal loads of x0 and the residual / store of the residual / store of z
-template <class ET, int CH, bool RES_F32, bool W_F32, bool NTL = false, bool NTS = false, bool NTZ = NTS>
+// SCALED: rowscale / colscale present (reference ln_fwd_kernels.cuh:99,123-125: x0 * rowscale[row], dropout, * colscale[col])
+template <class ET, int CH, bool RES_F32, bool W_F32, bool NTL = false, bool NTS = false, bool NTZ = NTS, bool SCALED = false>
 __global__ __launch_bounds__(256) void add_layer_norm_kernel(const LnParams p) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -96,6 +97,10 @@ __global__ __launch_bounds__(256) void add_layer_norm_kernel(const LnParams p) {
 
     float x[CH][4];
     float sum = 0.f;
+    float row_scale = 1.f;
+    if (SCALED && p.rowscale != nullptr)
+        row_scale = p.x0_f32 ? static_cast<const float *>(p.rowscale)[row]
+                             : to_f32<ET>(static_cast<const uint16_t *>(p.rowscale)[row]);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         const int col = (c * 64 + lane) * 4;
@@ -104,6 +109,10 @@ __global__ __launch_bounds__(256) void add_layer_norm_kernel(const LnParams p) {
         if (col < p.cols) {
             if (p.x0_f32) load4s<ET, true, NTL>(p.x0, base + col, x[c]);
             else load4s<ET, false, NTL>(p.x0, base + col, x[c]);
+            if (SCALED) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[c][i] *= row_scale;
+            }
             if (drop) {
                 uint32_t lo, hi, m = 0u;
                 dropout_bits4(rng, (uint32_t)row, (uint32_t)(col >> 2), lo, hi);
@@ -114,6 +123,12 @@ __global__ __launch_bounds__(256) void add_layer_norm_kernel(const LnParams p) {
                     m |= (keep ? 1u : 0u) << (8 * i);
                 }
                 if (p.dmask != nullptr) *reinterpret_cast<uint32_t *>(p.dmask + base + col) = m;
+            }
+            if (SCALED && p.colscale != nullptr) {
+                float cs[4];
+                load4<ET, W_F32>(p.colscale, col, cs);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[c][i] *= cs[i];
             }
             if (p.x1 != nullptr) {
                 float r[4];
@@ -172,8 +187,12 @@ static hipError_t launch_flags(const LnParams &p, hipStream_t stream) {
 #define BP_LN_NT 4
 #endif
     constexpr bool NTL = BP_LN_NT >= 2, NTS = BP_LN_NT == 1 || BP_LN_NT == 2 || BP_LN_NT == 4, NTZ = BP_LN_NT == 1 || BP_LN_NT == 2;
+    const bool scaled = p.rowscale != nullptr || p.colscale != nullptr;
 #define BP_LN_CASE(N) \
-    if (ch <= N) { hipLaunchKernelGGL((add_layer_norm_kernel<ET, N, RES_F32, W_F32, NTL, NTS, NTZ>), g, t, 0, stream, p); return hipGetLastError(); }
+    if (ch <= N) { \
+        if (scaled) hipLaunchKernelGGL((add_layer_norm_kernel<ET, N, RES_F32, W_F32, NTL, NTS, NTZ, true>), g, t, 0, stream, p); \
+        else hipLaunchKernelGGL((add_layer_norm_kernel<ET, N, RES_F32, W_F32, NTL, NTS, NTZ, false>), g, t, 0, stream, p); \
+        return hipGetLastError(); }
     BP_LN_CASE(1) BP_LN_CASE(2) BP_LN_CASE(3) BP_LN_CASE(4) BP_LN_CASE(6) BP_LN_CASE(8)
     BP_LN_CASE(12) BP_LN_CASE(16) BP_LN_CASE(24) BP_LN_CASE(32)
 #undef BP_LN_CASE
@@ -214,9 +233,11 @@ BP_DEV void wave_sum2(float &a, float &b) {
     }
 }
 
-template <class ET, int CH, bool RES_F32, bool W_F32>
+// SCALED: the forward had a rowscale and / or a colscale: dx0 = dx * rowscale * mask / (1 - p) * colscale,
+// dcolscale = sum over rows of dx * rowscale * mask / (1 - p) * x0 (reference ln_bwd_kernels.cuh:183-195)
+template <class ET, int CH, bool RES_F32, bool W_F32, bool SCALED = false>
 __global__ __launch_bounds__(256) void add_layer_norm_bwd_kernel(const LnBwdParams p) {
-    __shared__ float fold[2][CH * 256];
+    __shared__ float fold[SCALED ? 3 : 2][CH * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float inv_n = 1.f / (float)p.cols;
     const bool drop = p.drop_thr != 0u;
@@ -224,18 +245,31 @@ __global__ __launch_bounds__(256) void add_layer_norm_bwd_kernel(const LnBwdPara
     if (drop) rng = dropout_stream(p.rng_state, 0u);
 
     float g[CH][4], dg[CH][4], db[CH][4];
+    float cs[SCALED ? CH : 1][4], dcs[SCALED ? CH : 1][4];
+    const bool has_cs = SCALED && p.colscale != nullptr;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         const int col = (c * 64 + lane) * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { g[c][i] = 0.f; dg[c][i] = 0.f; db[c][i] = 0.f; }
-        if (col < p.cols) load4<ET, W_F32>(p.gamma, col, g[c]);
+        if (SCALED) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { cs[c][i] = 1.f; dcs[c][i] = 0.f; }
+        }
+        if (col < p.cols) {
+            load4<ET, W_F32>(p.gamma, col, g[c]);
+            if (has_cs) load4<ET, W_F32>(p.colscale, col, cs[c]);
+        }
     }
 
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < p.rows; row += (int64_t)p.n_wg * 4) {
         const int64_t base = row * p.cols;
         float x[CH][4], dy[CH][4];
         float sum = 0.f;
+        float row_scale = 1.f;
+        if (SCALED && p.rowscale != nullptr)
+            row_scale = p.x0_f32 ? static_cast<const float *>(p.rowscale)[row]
+                                 : to_f32<ET>(static_cast<const uint16_t *>(p.rowscale)[row]);
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const int col = (c * 64 + lane) * 4;
@@ -298,11 +332,25 @@ __global__ __launch_bounds__(256) void add_layer_norm_bwd_kernel(const LnBwdPara
                     for (int i = 0; i < 4; ++i) dx[i] += r[i];
                 }
                 if (p.dx1 != nullptr) store4<ET, RES_F32>(p.dx1, base + col, dx);
+                if (SCALED) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dx[i] *= row_scale;
+                }
                 if (drop) {   // x0 entered through dropout: its gradient passes the same mask and scale
                     uint32_t lo, hi;
                     dropout_bits4(rng, (uint32_t)row, (uint32_t)(col >> 2), lo, hi);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) dx[i] = dropout_u16(lo, hi, i) < p.drop_thr ? dx[i] * p.drop_scale : 0.f;
+                }
+                if (has_cs) {
+                    float x0v[4];
+                    if (p.x0_f32) load4<ET, true>(p.x0, base + col, x0v);
+                    else load4<ET, false>(p.x0, base + col, x0v);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        dcs[c][i] += dx[i] * x0v[i];
+                        dx[i] *= cs[c][i];
+                    }
                 }
                 if (p.x0_f32) store4<ET, true>(p.dx0, base + col, dx);
                 else store4<ET, false>(p.dx0, base + col, dx);
@@ -320,6 +368,7 @@ __global__ __launch_bounds__(256) void add_layer_norm_bwd_kernel(const LnBwdPara
                     const int idx = (c * 64 + lane) * 4 + i;
                     fold[0][idx] = (w == 0 ? 0.f : fold[0][idx]) + dg[c][i];
                     fold[1][idx] = (w == 0 ? 0.f : fold[1][idx]) + db[c][i];
+                    if (SCALED) fold[2][idx] = (w == 0 ? 0.f : fold[2][idx]) + dcs[c][i];
                 }
         }
         __syncthreads();
@@ -327,6 +376,7 @@ __global__ __launch_bounds__(256) void add_layer_norm_bwd_kernel(const LnBwdPara
     for (int col = threadIdx.x; col < p.cols; col += 256) {
         p.ws[(int64_t)blockIdx.x * p.cols + col] = fold[0][col];
         p.ws[((int64_t)kLnBwdMaxWg + blockIdx.x) * p.cols + col] = fold[1][col];
+        if (SCALED && has_cs) p.ws[((int64_t)2 * kLnBwdMaxWg + blockIdx.x) * p.cols + col] = fold[2][col];
     }
 }
 
@@ -334,30 +384,36 @@ __global__ __launch_bounds__(256) void add_layer_norm_bwd_kernel(const LnBwdPara
 // serial part is n_wg / 16 coalesced loads per thread, then a fixed-order fold through LDS.
 template <class ET, bool W_F32>
 __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const LnBwdParams p) {
-    __shared__ float part[2][16][64];
+    __shared__ float part[3][16][64];
     const int c = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + c;
-    float a = 0.f, b = 0.f;
+    const bool has_cs = p.dcolscale != nullptr;
+    float a = 0.f, b = 0.f, e = 0.f;
     if (col < p.cols) {
         for (int r = slice; r < p.n_wg; r += 16) {
             a += p.ws[(int64_t)r * p.cols + col];
             b += p.ws[((int64_t)kLnBwdMaxWg + r) * p.cols + col];
+            if (has_cs) e += p.ws[((int64_t)2 * kLnBwdMaxWg + r) * p.cols + col];
         }
     }
     part[0][slice][c] = a;
     part[1][slice][c] = b;
+    part[2][slice][c] = e;
     __syncthreads();
     if (slice != 0 || col >= p.cols) return;
     for (int s = 1; s < 16; ++s) {
         a += part[0][s][c];
         b += part[1][s][c];
+        e += part[2][s][c];
     }
     if (W_F32) {
         static_cast<float *>(p.dgamma)[col] = a;
         static_cast<float *>(p.dbeta)[col] = b;
+        if (has_cs) static_cast<float *>(p.dcolscale)[col] = e;
     } else {
         static_cast<uint16_t *>(p.dgamma)[col] = Elem<ET>::from_float(a);
         static_cast<uint16_t *>(p.dbeta)[col] = Elem<ET>::from_float(b);
+        if (has_cs) static_cast<uint16_t *>(p.dcolscale)[col] = Elem<ET>::from_float(e);
     }
 }
 
@@ -365,8 +421,12 @@ template <class ET, bool RES_F32, bool W_F32>
 static hipError_t launch_bwd_flags(const LnBwdParams &p, hipStream_t stream) {
     const int ch = (p.cols + 255) / 256;
     dim3 g((unsigned)p.n_wg), t(256);
+    const bool scaled = p.rowscale != nullptr || p.colscale != nullptr;
 #define BP_LNB_CASE(N) \
-    if (ch <= N) { hipLaunchKernelGGL((add_layer_norm_bwd_kernel<ET, N, RES_F32, W_F32>), g, t, 0, stream, p); } else
+    if (ch <= N) { \
+        if (scaled) hipLaunchKernelGGL((add_layer_norm_bwd_kernel<ET, N, RES_F32, W_F32, true>), g, t, 0, stream, p); \
+        else hipLaunchKernelGGL((add_layer_norm_bwd_kernel<ET, N, RES_F32, W_F32, false>), g, t, 0, stream, p); \
+    } else
     BP_LNB_CASE(1) BP_LNB_CASE(2) BP_LNB_CASE(3) BP_LNB_CASE(4) BP_LNB_CASE(6) BP_LNB_CASE(8)
     { return hipErrorNotSupported; }
 #undef BP_LNB_CASE

@@ -478,11 +478,22 @@ int bp_dropout_add_layer_norm(const void *x0, const void *x1, const void *gamma,
                               void *x_out, uint8_t *dmask, int64_t rows, int cols, float epsilon, int dtype,
                               int x0_is_f32, int x1_is_f32, int xout_is_f32, int w_is_f32,
                               float p_dropout, const uint64_t *rng_state, bp_stream_t stream) {
+    return bp_dropout_add_layer_norm_scaled(x0, x1, gamma, beta, nullptr, nullptr, z, x_out, dmask, rows, cols, epsilon,
+                                            dtype, x0_is_f32, x1_is_f32, xout_is_f32, w_is_f32, p_dropout, rng_state, stream);
+}
+
+int bp_dropout_add_layer_norm_scaled(const void *x0, const void *x1, const void *gamma, const void *beta,
+                                     const void *rowscale, const void *colscale, void *z, void *x_out, uint8_t *dmask,
+                                     int64_t rows, int cols, float epsilon, int dtype, int x0_is_f32, int x1_is_f32,
+                                     int xout_is_f32, int w_is_f32, float p_dropout, const uint64_t *rng_state,
+                                     bp_stream_t stream) {
     if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
     if (rows <= 0 || rows > 0xffffffffLL || cols <= 0 || cols % 4 != 0 || cols > 8192) return BP_ERR_SHAPE;
     if (x0 == nullptr || gamma == nullptr || beta == nullptr || z == nullptr) return BP_ERR_SHAPE;
     if (!aligned16(x0) || !aligned16(gamma) || !aligned16(beta) || !aligned16(z) ||
         (x1 != nullptr && !aligned16(x1)) || (x_out != nullptr && !aligned16(x_out)) ||
+        (colscale != nullptr && !aligned16(colscale)) ||
+        (rowscale != nullptr && (reinterpret_cast<uintptr_t>(rowscale) & (x0_is_f32 ? 3u : 1u)) != 0) ||
         (dmask != nullptr && (reinterpret_cast<uintptr_t>(dmask) & 3u) != 0))
         return BP_ERR_SHAPE;
     if (!(isfinite(epsilon) && epsilon >= 0.f)) return BP_ERR_SCALE;
@@ -496,6 +507,7 @@ int bp_dropout_add_layer_norm(const void *x0, const void *x1, const void *gamma,
     p.x1_f32 = x1_is_f32 ? 1 : 0; p.xo_f32 = xout_is_f32 ? 1 : 0; p.w_f32 = w_is_f32 ? 1 : 0;
     p.x0_f32 = x0_is_f32 ? 1 : 0;
     p.dmask = dmask; p.rng_state = rng_state;
+    p.rowscale = rowscale; p.colscale = colscale;
     if (!dropout_args(p_dropout, rng_state, p.drop_thr, p.drop_scale)) return BP_ERR_DROPOUT;
     hipError_t e = bp::launch_add_layer_norm(p, dtype, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
@@ -526,14 +538,34 @@ int bp_dropout_add_layer_norm_bwd(const void *dz, const void *dx_in, const void 
                                   void *dx0, void *dx1, void *dgamma, void *dbeta, float *ws,
                                   int64_t rows, int cols, float epsilon, int dtype, int x0_is_f32, int res_is_f32,
                                   int w_is_f32, float p_dropout, const uint64_t *rng_state, bp_stream_t stream) {
+    // (the unscaled entry point keeps its documented workspace contract: 2 * BP_LN_BWD_WS_ROWS * cols floats)
+    return bp_dropout_add_layer_norm_scaled_bwd(dz, dx_in, x, nullptr, gamma, nullptr, nullptr, dx0, dx1, dgamma, dbeta,
+                                                nullptr, ws, bp_ln_bwd_ws_floats(cols, 0), rows, cols, epsilon, dtype,
+                                                x0_is_f32, res_is_f32, w_is_f32, p_dropout, rng_state, stream);
+}
+
+int64_t bp_ln_bwd_ws_floats(int cols, int has_colscale) {
+    if (cols <= 0) return 0;
+    return (int64_t)(has_colscale ? 3 : 2) * bp::kLnBwdMaxWg * cols;
+}
+
+int bp_dropout_add_layer_norm_scaled_bwd(const void *dz, const void *dx_in, const void *x, const void *x0,
+                                         const void *gamma, const void *rowscale, const void *colscale,
+                                         void *dx0, void *dx1, void *dgamma, void *dbeta, void *dcolscale,
+                                         float *ws, int64_t ws_floats, int64_t rows, int cols, float epsilon, int dtype,
+                                         int x0_is_f32, int res_is_f32, int w_is_f32, float p_dropout,
+                                         const uint64_t *rng_state, bp_stream_t stream) {
     static_assert(BP_LN_BWD_WS_ROWS == bp::kLnBwdMaxWg, "workspace rows");
     if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
     if (rows <= 0 || rows > 0xffffffffLL || cols <= 0 || cols % 4 != 0 || cols > 2048) return BP_ERR_SHAPE;
     if (!dz || !x || !gamma || !dx0 || !dgamma || !dbeta || !ws) return BP_ERR_SHAPE;
-    const void *ptrs[] = {dz, dx_in, x, gamma, dx0, dx1, dgamma, dbeta, ws};
+    if (colscale != nullptr && (x0 == nullptr || dcolscale == nullptr)) return BP_ERR_SHAPE;   // (layer_norm.py:36-37)
+    const void *ptrs[] = {dz, dx_in, x, x0, gamma, colscale, dx0, dx1, dgamma, dbeta, dcolscale, ws};
     for (const void *ptr : ptrs) if (ptr != nullptr && !aligned16(ptr)) return BP_ERR_SHAPE;
+    if (rowscale != nullptr && (reinterpret_cast<uintptr_t>(rowscale) & (x0_is_f32 ? 3u : 1u)) != 0) return BP_ERR_SHAPE;
     if (!(isfinite(epsilon) && epsilon >= 0.f)) return BP_ERR_SCALE;
     if (x0_is_f32 && !res_is_f32) return BP_ERR_DTYPE;
+    if (ws_floats < bp_ln_bwd_ws_floats(cols, colscale != nullptr)) return BP_ERR_WORKSPACE;
     bp::LnBwdParams p{};
     p.dz = dz; p.dx_in = dx_in; p.x = x; p.gamma = gamma; p.dx0 = dx0; p.dx1 = dx1;
     p.dgamma = dgamma; p.dbeta = dbeta; p.ws = ws;
@@ -541,6 +573,7 @@ int bp_dropout_add_layer_norm_bwd(const void *dz, const void *dx_in, const void 
     p.n_wg = (int)((rows + 3) / 4 < bp::kLnBwdMaxWg ? (rows + 3) / 4 : bp::kLnBwdMaxWg);
     p.res_f32 = res_is_f32 ? 1 : 0; p.w_f32 = w_is_f32 ? 1 : 0; p.x0_f32 = x0_is_f32 ? 1 : 0;
     p.rng_state = rng_state;
+    p.rowscale = rowscale; p.colscale = colscale; p.x0 = x0; p.dcolscale = colscale != nullptr ? dcolscale : nullptr;
     if (!dropout_args(p_dropout, rng_state, p.drop_thr, p.drop_scale)) return BP_ERR_DROPOUT;
     hipError_t e = bp::launch_add_layer_norm_bwd(p, dtype, static_cast<hipStream_t>(stream));
     if (e == hipErrorNotSupported) return BP_ERR_SHAPE;

@@ -161,6 +161,8 @@ struct LnParams {
     const uint64_t *rng_state;   // dropout on x0 (bp_philox.h); drop_thr == 0: none
     uint32_t drop_thr;
     float drop_scale;
+    const void *rowscale;        // optional (rows) in x0's dtype: x0 row r is multiplied by rowscale[r] (DropPath)
+    const void *colscale;        // optional (cols) in gamma's dtype: column c by colscale[c] (LayerScale)
 };
 
 hipError_t launch_add_layer_norm(const LnParams &p, int dtype, hipStream_t stream);
@@ -174,7 +176,7 @@ struct LnBwdParams {
     void *dx0;                // (rows, cols) 16-bit
     void *dx1;                // (rows, cols) residual dtype, may be NULL (same values as dx0)
     void *dgamma, *dbeta;     // (cols) gamma's dtype
-    float *ws;                // (2, kLnBwdMaxWg, cols) fp32 partial sums
+    float *ws;                // (2, kLnBwdMaxWg, cols) fp32 partial sums; (3, ...) with a colscale
     int64_t rows;
     int cols, n_wg;
     int res_f32, w_f32;
@@ -183,6 +185,9 @@ struct LnBwdParams {
     const uint64_t *rng_state;   // the forward's dropout state: dx0 = dropout-masked, rescaled dx
     uint32_t drop_thr;
     float drop_scale;
+    const void *rowscale, *colscale;   // the forward's (optional)
+    const void *x0;              // the forward's x0 (dz's dtype): needed for dcolscale only
+    void *dcolscale;             // (cols) gamma's dtype, with colscale
 };
 hipError_t launch_add_layer_norm_bwd(const LnBwdParams &p, int dtype, hipStream_t stream);
 // bias + tanh-GELU forward / backward and bias-gradient column sums (bias_gelu.hip)

@@ -28,10 +28,11 @@
 extern "C" {
 #endif
 
-#define BP_ABI_VERSION 4   /* 2: *_dropout entry points added; 3: bias/GELU + column-sum entry points added, the
+#define BP_ABI_VERSION 5   /* 2: *_dropout entry points added; 3: bias/GELU + column-sum entry points added, the
                               persistent sense-mix launches take a caller-owned `queue_ws`; 4: bp_flash_bwd* take the
                               size of `dsum_ws` (bp_flash_bwd_ws_floats) and check it, queue_ws == NULL is refused
-                              while the stream is capturing (BP_ERR_QUEUE_WS) */
+                              while the stream is capturing (BP_ERR_QUEUE_WS); 5: bp_dropout_add_layer_norm_scaled{,_bwd}
+                              (rowscale / colscale of the reference's dropout_add_ln) added */
 
 /* element type of q/k/v/out/content tensors */
 #define BP_DTYPE_F16 0
@@ -380,6 +381,33 @@ int bp_dropout_add_layer_norm_bwd(const void *dz, const void *dx_in, const void 
                                   void *dx0, void *dx1, void *dgamma, void *dbeta, float *ws,
                                   int64_t rows, int cols, float epsilon, int dtype, int x0_is_f32, int res_is_f32,
                                   int w_is_f32, float p_dropout, const uint64_t *rng_state, bp_stream_t stream);
+
+/*
+ * bp_dropout_add_layer_norm_scaled / _scaled_bwd -- bp_dropout_add_layer_norm{,_bwd} with the two scale vectors of the
+ * reference's dropout_add_ln_fwd / _bwd (csrc/layer_norm/ln_api.cpp:83-254,256-408; kernels ln_fwd_kernels.cuh:99,123-125,
+ * ln_bwd_kernels.cuh:183-195; Python side flash_attn/ops/layer_norm.py:207-217 `rowscale`, `layerscale`):
+ *   x = dropout(x0 * rowscale[row]) / (1 - p) * colscale[col] + x1 ;  z = LayerNorm(x)
+ *   dx0 = dx * rowscale[row] * mask / (1 - p) * colscale[col] ;  dcolscale[col] = sum_rows dx * rowscale[row] * mask / (1 - p) * x0
+ *   rowscale  (rows) in x0's dtype (fp32 when x0_is_f32), or NULL      -- DropPath: Bernoulli(survival) / survival per row
+ *   colscale  (cols) in gamma's dtype, or NULL                        -- LayerScale
+ *   x0        backward only, the forward's x0 (needed for dcolscale; may be NULL without a colscale)
+ *   dcolscale (cols) in gamma's dtype; required with a colscale
+ *   ws        fp32 workspace of `ws_floats` elements >= bp_ln_bwd_ws_floats(cols, colscale != NULL) (BP_ERR_WORKSPACE otherwise)
+ * With both vectors NULL these are the unscaled entry points (which forward to them).  The `subset` arguments of the
+ * reference (x0_subset / out_subset / rowscale_const, a ViT token-dropping feature) are not part of this ABI.
+ */
+int64_t bp_ln_bwd_ws_floats(int cols, int has_colscale);
+int bp_dropout_add_layer_norm_scaled(const void *x0, const void *x1, const void *gamma, const void *beta,
+                                     const void *rowscale, const void *colscale, void *z, void *x_out, uint8_t *dmask,
+                                     int64_t rows, int cols, float epsilon, int dtype, int x0_is_f32, int x1_is_f32,
+                                     int xout_is_f32, int w_is_f32, float p_dropout, const uint64_t *rng_state,
+                                     bp_stream_t stream);
+int bp_dropout_add_layer_norm_scaled_bwd(const void *dz, const void *dx_in, const void *x, const void *x0,
+                                         const void *gamma, const void *rowscale, const void *colscale,
+                                         void *dx0, void *dx1, void *dgamma, void *dbeta, void *dcolscale,
+                                         float *ws, int64_t ws_floats, int64_t rows, int cols, float epsilon, int dtype,
+                                         int x0_is_f32, int res_is_f32, int w_is_f32, float p_dropout,
+                                         const uint64_t *rng_state, bp_stream_t stream);
 
 /*
  * bp_xentropy_fwd / bp_xentropy_bwd -- fused softmax cross-entropy over vocabulary-sized rows.

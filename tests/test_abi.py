@@ -102,6 +102,15 @@ def test_argument_validation_returns_before_any_launch():
     assert h.bp_attn_probs_dropout(p, p, p, p, 1, 1, 64, 16, 16, 1, 1, 1, 1, 1, 1, 16, 1, 1, 1, 0.125, 1, 1,
                                    2.0, p, null) == -7
 
+    # fused LayerNorm with rowscale / colscale (ABI 5): a colscale without x0 / dcolscale, a workspace of the unscaled size
+    ln = (p, p, p)
+    assert h.bp_ln_bwd_ws_floats(768, 0) == 2 * 1024 * 768 and h.bp_ln_bwd_ws_floats(768, 1) == 3 * 1024 * 768
+    assert h.bp_dropout_add_layer_norm_scaled_bwd(p, null, p, null, p, null, p, p, null, p, p, p, p, 3 * 1024 * 768,
+                                                  16, 768, 1e-5, 1, 0, 1, 1, 0.0, null, null) == -3
+    assert h.bp_dropout_add_layer_norm_scaled_bwd(p, null, p, p, p, null, p, p, null, p, p, p, p, 2 * 1024 * 768,
+                                                  16, 768, 1e-5, 1, 0, 1, 1, 0.0, null, null) == -9
+    assert h.bp_dropout_add_layer_norm_scaled(p, null, p, p, ctypes.c_void_p(0x1001), null, p, null, null, 16, 768, 1e-5,
+                                              1, 0, 0, 0, 1, 0.0, null, null) == -3          # misaligned rowscale
     # fused sense-mix backward: d_k not a multiple of 8, d_out not a multiple of 8, null dcontent, odd stride, bad scale
     mix_st = (64,) * 9
     assert h.bp_sense_mix_dc(p, p, p, p, 1, 16, 4, 10, 64, *mix_st, 0.25, 1, null, null) == -2

@@ -143,9 +143,11 @@ def test_mha_module_train_mode_uses_kernel_dropout():
 
 # ---------------------------------------------------------------------------------------------
 # fused dropout + add + LayerNorm: port of the reference's tests/ops/test_dropout_layer_norm.py::
-# test_dropout_layer_norm_training (no rowscale / colscale rows), its bounds: out and dx <= 4x, dgamma / dbeta <= 2x the
+# test_dropout_layer_norm_training (rowscale / colscale rows included since round 4), its bounds: out and dx <= 4x, dgamma / dbeta <= 2x the
 # error of the same computation in plain PyTorch at the input dtype, all against fp32 (:100-114)
 # ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('has_colscale', [False, True])
+@pytest.mark.parametrize('has_rowscale', [False, True])
 @pytest.mark.parametrize('has_residual', [True, False])
 @pytest.mark.parametrize('dropout_p', [0.37, 0.0])
 @pytest.mark.parametrize('weight_dtype', [torch.float32, torch.float16])
@@ -154,15 +156,28 @@ def test_mha_module_train_mode_uses_kernel_dropout():
                           (torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16),
                           (torch.bfloat16, torch.float32)])
 @pytest.mark.parametrize('hidden_size', [192, 384, 640, 768, 1024, 1600, 2048])
-def test_dropout_layer_norm_training(hidden_size, input_dtype, residual_dtype, weight_dtype, dropout_p, has_residual):
+def test_dropout_layer_norm_training(hidden_size, input_dtype, residual_dtype, weight_dtype, dropout_p, has_residual,
+                                     has_rowscale, has_colscale):
+    """has_rowscale / has_colscale: the DropPath / LayerScale arguments of the reference's sweep
+    (tests/ops/test_dropout_layer_norm.py:31-60,113-114), on three widths."""
     from flash_attn.ops.layer_norm import DropoutAddLayerNorm, dropout_add_layer_norm
     if weight_dtype == torch.float16 and input_dtype == torch.bfloat16:
         pytest.skip('not supported upstream either')
+    if (has_rowscale or has_colscale) and hidden_size not in (384, 768, 1600):
+        pytest.skip('scaled variants run on three widths')
     torch.random.manual_seed(0)
     batch_size, seqlen = 8, 512
     x0_pt = torch.randn(batch_size, seqlen, hidden_size, device=DEV, dtype=input_dtype, requires_grad=True)
     x0 = x0_pt.detach().clone().requires_grad_()
     x0_ref = x0_pt.detach().clone().float().requires_grad_()
+    colscale = rowscale = None
+    if has_colscale:
+        colscale = torch.randn(hidden_size, device=DEV, dtype=weight_dtype, requires_grad=True)
+        colscale_pt = colscale.detach().clone().requires_grad_()
+        colscale_ref = colscale.detach().clone().float().requires_grad_()
+    if has_rowscale:
+        survival_rate = 0.87
+        rowscale = torch.empty(batch_size, seqlen, device=DEV, dtype=input_dtype).bernoulli_(survival_rate) / survival_rate
     if has_residual:
         x1_pt = torch.randn_like(x0, dtype=residual_dtype, requires_grad=True)
         x1 = x1_pt.detach().clone().requires_grad_()
@@ -180,8 +195,15 @@ def test_dropout_layer_norm_training(hidden_size, input_dtype, residual_dtype, w
         model_ref.weight.copy_(model_pt.weight)
         model_ref.bias.copy_(model_pt.bias)
     residual_in_fp32 = (not has_residual) and residual_dtype == torch.float32
-    out, dmask = dropout_add_layer_norm(x0, x1, model.weight, model.bias, model.p, model.epsilon,
-                                        residual_in_fp32=residual_in_fp32, return_dropout_mask=True)
+    x0_scaled_pt, x0_scaled_ref = x0_pt, x0_ref
+    if has_rowscale:
+        x0_scaled_pt = x0_scaled_pt * rowscale.unsqueeze(-1)
+        x0_scaled_ref = x0_scaled_ref * rowscale.unsqueeze(-1)
+    if has_colscale:
+        x0_scaled_pt = x0_scaled_pt * colscale_pt
+        x0_scaled_ref = x0_scaled_ref * colscale_ref
+    out, dmask = dropout_add_layer_norm(x0, x1, model.weight, model.bias, model.p, model.epsilon, rowscale=rowscale,
+                                        layerscale=colscale, residual_in_fp32=residual_in_fp32, return_dropout_mask=True)
     assert out.dtype == input_dtype and dmask.dtype == torch.uint8 and dmask.shape == x0.shape
     frac = 1 - dmask.float().mean().item()
     assert abs(frac - dropout_p) < 0.005, frac
@@ -191,11 +213,11 @@ def test_dropout_layer_norm_training(hidden_size, input_dtype, residual_dtype, w
         want = P.rows_keep_mask(seed, offset, 64, hidden_size, dropout_p)
         assert np.array_equal(dmask.flatten(0, 1)[:64].cpu().numpy().astype(bool), want)
     if has_residual:
-        residual_pt = ((x0_pt.float() * dmask.float()) / (1 - dropout_p) + x1_pt.float()).to(dtype=residual_dtype)
-        residual_ref = (x0_ref * dmask.float()) / (1 - dropout_p) + x1_ref
+        residual_pt = ((x0_scaled_pt.float() * dmask.float()) / (1 - dropout_p) + x1_pt.float()).to(dtype=residual_dtype)
+        residual_ref = (x0_scaled_ref * dmask.float()) / (1 - dropout_p) + x1_ref
     else:
-        residual_pt = ((x0_pt.float() * dmask.float()) / (1 - dropout_p)).to(dtype=residual_dtype)
-        residual_ref = (x0_ref * dmask.float()) / (1 - dropout_p)
+        residual_pt = ((x0_scaled_pt.float() * dmask.float()) / (1 - dropout_p)).to(dtype=residual_dtype)
+        residual_ref = (x0_scaled_ref * dmask.float()) / (1 - dropout_p)
     out_pt = model_pt(residual_pt.to(dtype=weight_dtype)).to(dtype=input_dtype)
     out_ref = model_ref(residual_ref)
     assert (out - out_ref).abs().max() <= 4 * (out_pt - out_ref).abs().max() + 1e-4
@@ -211,6 +233,9 @@ def test_dropout_layer_norm_training(hidden_size, input_dtype, residual_dtype, w
         2 * (model_pt.weight.grad - model_ref.weight.grad).abs().max() + 3e-5
     assert (model.bias.grad - model_ref.bias.grad).abs().max() <= \
         2 * (model_pt.bias.grad - model_ref.bias.grad).abs().max() + 3e-5
+    if has_colscale:
+        assert (colscale.grad - colscale_ref.grad).abs().max() <= \
+            2 * (colscale_pt.grad - colscale_ref.grad).abs().max() + 2e-4
 
 
 def test_backpack_train_mode_with_the_reference_dropout_defaults_under_autocast():
