@@ -20,7 +20,8 @@ _lib = None
 
 # Backward routes that are NOT the fused HIP kernels -- autograd through an eager recomputation of the attention for head
 # dims the HIP backward lacks (flash_attn_interface._FlashAttnFuncBase._bwd), the alpha-rebuilding backward of the sense
-# mix for key-weighted / non-multiple-of-8 shapes (_sense_mix_backward_rebuild) -- are opt-in: without
+# mix for key-weighted / non-multiple-of-8 shapes (_sense_mix_backward_rebuild), the eager LayerNorm backward for rows wider
+# than 2048 columns (flash_attn/ops/layer_norm.py) -- are opt-in: without
 # `with bp_hip.allow_eager_fallback():` they raise instead of running silently (round-3 review: "no fallback" must mean it).
 _eager_fallback = False
 

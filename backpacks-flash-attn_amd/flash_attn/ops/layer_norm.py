@@ -8,7 +8,8 @@ AMP case: fp32 embedding output into the first LayerNorm).  rowscale / layerscal
 :102-150,207-217) are inside the same kernels (bp_dropout_add_layer_norm_scaled{,_bwd}, round 4) although no Backpack /
 GPT-2 config uses them; the `subset` variant (:153-200, ViT token dropping) is not provided.  Backward is the HIP kernel
 for rows up to 2048 columns
-(statistics recomputed from the saved summed stream); wider rows differentiate the eager expression."""
+(statistics recomputed from the saved summed stream); wider rows raise unless the caller opted in to differentiating
+the eager expression (`bp_hip.allow_eager_fallback()`)."""
 import torch
 import torch.nn.functional as F
 from torch.nn import init
@@ -60,6 +61,10 @@ class DropoutAddLayerNormFn(torch.autograd.Function):
                     (rest[0] if colscale is not None else None), None, None, None, None, None)
         if ctx.dropout_p > 0.0 or rowscale is not None or colscale is not None:
             raise RuntimeError('dropout_add_layer_norm (gfx950 build): fused dropout / rowscale / layerscale need <= 2048 columns')
+        if not bp_hip.eager_fallback_allowed():
+            raise RuntimeError('dropout_add_layer_norm (gfx950 build): the HIP backward takes rows of up to 2048 columns (got '
+                               '%d); differentiating the eager expression instead is opt-in: '
+                               '`with bp_hip.allow_eager_fallback():` around backward()' % xsum.shape[-1])
         with torch.enable_grad():   # wide rows: differentiate the eager expression
             a = xsum.detach().float().requires_grad_()
             g, bt = gamma.detach().requires_grad_(), beta.detach().requires_grad_()
