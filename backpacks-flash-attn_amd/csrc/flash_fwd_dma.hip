@@ -35,9 +35,9 @@
 #include "bp_philox.h"
 
 // waves per SIMD the register allocator must leave room for (512 VGPRs per SIMD lane): the trunk shapes
-// (head_dim <= 64) run three workgroups per CU
+// (head_dim <= 64; <= 96 without dropout since the odd K pitch of round 4) run at least three workgroups per CU
 #ifndef BP_FLASH_MINWAVES
-#define BP_FLASH_MINWAVES(NV) ((NV) <= 2 ? 3 : 1)
+#define BP_FLASH_MINWAVES(NV, DROP) ((NV) <= 2 || ((NV) == 3 && !(DROP)) ? 3 : 1)
 #endif
 
 namespace bp {
@@ -65,16 +65,25 @@ template <int KD, int NV, bool HAS_V>
 struct FlashDmaCfg {
     static constexpr int NWAVE = (BP_FWD_NWAVE == 8 && KD <= 4 && KD >= 3 && (!HAS_V || NV >= 2)) ? 8 : 4;
     static constexpr int BM = 32 * NWAVE, BN = 64, NT = 64 * NWAVE, NSTAGE = 2;
-    static constexpr int KROW = KD <= 4 ? 128 : 256;
-    static constexpr int KSLOTS = KROW / 16;
+    // K row pitch in LDS.  Head dims up to 64 and 128 fill a power-of-two pitch (128 / 256 bytes) and XOR-swizzle the
+    // 16-byte slots (k_swz); the widths in between (d_h = 80: Mini; 96, 112) take an ODD number of slots, 2 KD + 1: the
+    // quad-bank of (row, slot) is (row * KSLOTS + slot) mod 16, distinct for the 16 rows of every ds_read_b128 lane group
+    // without any swizzle, and the tile shrinks from 16 KB to 11 / 13 / 15 KB -- at d_h = 80 that is 47 KB per workgroup
+    // instead of 57 KB, i.e. three workgroups per CU instead of two (round 4, BP_FWD_ODD_PITCH).
+#ifndef BP_FWD_ODD_PITCH
+#define BP_FWD_ODD_PITCH 1
+#endif
+    static constexpr bool ODD = BP_FWD_ODD_PITCH && KD >= 5 && KD <= 7;
+    static constexpr int KSLOTS = KD <= 4 ? 8 : ODD ? 2 * KD + 1 : 16;
+    static constexpr int KROW = KSLOTS * 16;
     static constexpr int VROW = NV * 64;
     static constexpr int VCH = NV * 4;
     static constexpr int KTILE = BN * KROW;
     static constexpr int VTILE = HAS_V ? BN * VROW : 0;
     static constexpr int STAGE = KTILE + VTILE;
-    static constexpr int K_DMA = KTILE / 1024 / NWAVE;            // 2 or 4 per wave per tile
+    static constexpr int K_PIECES = KTILE / 1024;                 // 1-KiB DMA pieces per tile (8, 11, 13, 15 or 16)
+    static constexpr int K_DMA = (K_PIECES + NWAVE - 1) / NWAVE;  // per wave per tile (the last wave may own fewer)
     static constexpr int V_DMA = HAS_V ? VTILE / 1024 / NWAVE : 0;  // 1..4
-    static constexpr int K_ROWS_PER_DMA = 1024 / KROW;
 };
 
 template <class ET> struct ProbLimit;   // largest tile row sum the fast body accepts (see header)
@@ -164,9 +173,11 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
     uint32_t k_voff[C::K_DMA];
 #pragma unroll
     for (int j = 0; j < C::K_DMA; ++j) {
-        const int row = (wave * C::K_DMA + j) * C::K_ROWS_PER_DMA + lane / C::KSLOTS;
+        // lane's 16 bytes of piece (wave * K_DMA + j): linear 16-byte slot g of the tile image -> (row, stored slot)
+        const int g = (wave * C::K_DMA + j) * 64 + lane;
+        const int row = g / C::KSLOTS;
         k_row[j] = row;
-        k_col[j] = ((lane % C::KSLOTS) ^ k_swz<C::KROW>(row)) * 8;
+        k_col[j] = (C::ODD ? g - row * C::KSLOTS : (g - row * C::KSLOTS) ^ k_swz<C::KROW>(row)) * 8;
         k_voff[j] = (uint32_t)(row * p.k_rs + k_col[j]) * 2u;
     }
     int v_row[HAS_V ? C::V_DMA : 1], v_col[HAS_V ? C::V_DMA : 1];
@@ -197,9 +208,9 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
         if (__builtin_expect(kb == kb_partial, 0)) {
 #pragma unroll
             for (int j = 0; j < C::K_DMA; ++j) {
-                const int row = (wave * C::K_DMA + j) * C::K_ROWS_PER_DMA + lane / C::KSLOTS;
+                const int row = ((wave * C::K_DMA + j) * 64 + lane) / C::KSLOTS;
                 const uint32_t back = (uint32_t)(max(row - last_row, 0) * p.k_rs) * 2u;
-                if (FULLD || k_col[j] < p.d)
+                if (wave * C::K_DMA + j < C::K_PIECES && (FULLD || k_col[j] < p.d))
                     dma16_s(kt, k_voff[j] - back, __builtin_amdgcn_readfirstlane(stage + (wave * C::K_DMA + j) * 1024));
             }
             if (HAS_V) {
@@ -215,7 +226,7 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
         } else {
 #pragma unroll
             for (int j = 0; j < C::K_DMA; ++j)
-                if (FULLD || k_col[j] < p.d)
+                if (wave * C::K_DMA + j < C::K_PIECES && (FULLD || k_col[j] < p.d))
                     dma16_s(kt, k_voff[j], __builtin_amdgcn_readfirstlane(stage + (wave * C::K_DMA + j) * 1024));
             if (HAS_V) {
 #pragma unroll
@@ -240,7 +251,8 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
 
     int k_read_off[KD];
 #pragma unroll
-    for (int s = 0; s < KD; ++s) k_read_off[s] = l31 * C::KROW + (((2 * s + hh) ^ k_swz<C::KROW>(l31)) * 16);
+    for (int s = 0; s < KD; ++s)
+        k_read_off[s] = l31 * C::KROW + (C::ODD ? 2 * s + hh : (2 * s + hh) ^ k_swz<C::KROW>(l31)) * 16;
     int v_read_off[HAS_V ? NV : 1];
     if (HAS_V) {
         const int v_row_lane = 4 * hh + ((lane & 15) >> 2);
@@ -519,7 +531,7 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
 // n+1 key blocks, nothing waits, and both tiles still belong to one group, i.e. one XCD's L2 holds their K/V.
 template <class ET, int KD, int NV, bool HAS_V, bool FULLD, bool DROP>
 __global__ __launch_bounds__((FlashDmaCfg<KD, NV, HAS_V>::NT),
-                             (FlashDmaCfg<KD, NV, HAS_V>::NWAVE == 8 ? 4 : BP_FLASH_MINWAVES(NV)))
+                             (FlashDmaCfg<KD, NV, HAS_V>::NWAVE == 8 ? 4 : BP_FLASH_MINWAVES(NV, DROP)))
 void flash_fwd_dma_kernel(const FlashParams p) {
     using C = FlashDmaCfg<KD, NV, HAS_V>;
     __shared__ __attribute__((aligned(16))) char smem[C::NSTAGE * C::STAGE];
