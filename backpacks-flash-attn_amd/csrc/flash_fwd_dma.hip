@@ -65,16 +65,17 @@ template <int KD, int NV, bool HAS_V>
 struct FlashDmaCfg {
     static constexpr int NWAVE = (BP_FWD_NWAVE == 8 && KD <= 4 && KD >= 3 && (!HAS_V || NV >= 2)) ? 8 : 4;
     static constexpr int BM = 32 * NWAVE, BN = 64, NT = 64 * NWAVE, NSTAGE = 2;
-    // K row pitch in LDS.  Head dims up to 64 and 128 fill a power-of-two pitch (128 / 256 bytes) and XOR-swizzle the
-    // 16-byte slots (k_swz); the widths in between (d_h = 80: Mini; 96, 112) take an ODD number of slots, 2 KD + 1: the
+    // K row pitch in LDS.  Head dims 64 and 128 fill a power-of-two pitch (128 / 256 bytes) and XOR-swizzle the
+    // 16-byte slots (k_swz); every other width (d_h = 80: Mini; the senses' d_k = 48 / 24 / 16) takes an ODD number of slots,
+    // 2 KD + 1 (a narrow K tile is also fewer DMA pieces: d_k = 16 moves 3 KB per tile instead of 8): the
     // quad-bank of (row, slot) is (row * KSLOTS + slot) mod 16, distinct for the 16 rows of every ds_read_b128 lane group
     // without any swizzle, and the tile shrinks from 16 KB to 11 / 13 / 15 KB -- at d_h = 80 that is 47 KB per workgroup
     // instead of 57 KB, i.e. three workgroups per CU instead of two (round 4, BP_FWD_ODD_PITCH).
 #ifndef BP_FWD_ODD_PITCH
 #define BP_FWD_ODD_PITCH 1
 #endif
-    static constexpr bool ODD = BP_FWD_ODD_PITCH && KD >= 5 && KD <= 7;
-    static constexpr int KSLOTS = KD <= 4 ? 8 : ODD ? 2 * KD + 1 : 16;
+    static constexpr bool ODD = BP_FWD_ODD_PITCH && KD != 4 && KD != 8;
+    static constexpr int KSLOTS = ODD ? 2 * KD + 1 : KD <= 4 ? 8 : 16;
     static constexpr int KROW = KSLOTS * 16;
     static constexpr int VROW = NV * 64;
     static constexpr int VCH = NV * 4;
