@@ -67,3 +67,38 @@ def test_hot_kernel_has_no_scratch(table, entry):
 def test_resource_table_lists_every_object(table):
     assert len(table) > 50
     assert all('vgpr_count' in k and 'sgpr_spill_count' in k for k in table.values())
+
+
+@pytest.mark.parametrize('obj', ['flash_fwd_dma.o', 'flash_bwd.o', 'sense_mix_dma.o', 'sense_mix_bwd.o'])
+def test_no_instruction_reads_m0_besides_the_lds_dma(obj):
+    """csrc/bp_dma.h: `dma16_s` writes M0 and names it as clobbered instead of saving and restoring it (two scalar moves per
+    1-KiB piece less).  That is only sound while no compiler-generated instruction in these kernels READS M0 -- relative
+    register indexing (v_movrel / s_movrel / s_set_gpr_idx), s_sendmsg, v_interp -- so the disassembly of every code object
+    that uses the helper is checked for them (advisor, round 3).  Every textual use of m0 must be an `s_mov_b32` of our own
+    DMA statements: the write in front of the LDS-DMA instruction (which reads it implicitly), or the save / restore pair
+    of the `dma16` / `dma4` forms."""
+    import subprocess
+    import tempfile
+    if not KR.tools_available() or not os.path.exists(os.path.join(KR.LLVM, 'llvm-objdump')):
+        pytest.skip('llvm tools not found under /opt/rocm')
+    path = os.path.join(KR.BUILD, obj)
+    if not os.path.exists(path):
+        pytest.skip('objects not built')
+    with tempfile.TemporaryDirectory() as tmp:
+        fat, co = os.path.join(tmp, 'fat.bin'), os.path.join(tmp, 'dev.co')
+        KR._run(os.path.join(KR.LLVM, 'llvm-objcopy'), '--dump-section', '.hip_fatbin=' + fat, path)
+        KR._run(os.path.join(KR.LLVM, 'clang-offload-bundler'), '--unbundle', '--type=o', '--targets=' + KR.TARGET,
+                '--input=' + fat, '--output=' + co)
+        text = subprocess.run([os.path.join(KR.LLVM, 'llvm-objdump'), '-d', '--mcpu=gfx950', co], capture_output=True,
+                              text=True, check=True).stdout
+    forbidden = ('v_movrel', 's_movrel', 's_set_gpr_idx', 's_sendmsg', 'v_interp_')
+    m0_users = set()
+    for line in text.splitlines():
+        ops = line.split('//')[0].split()
+        if not ops:
+            continue
+        assert not ops[0].startswith(forbidden), line
+        if any(tok.strip(',') == 'm0' for tok in ops[1:]):
+            m0_users.add(ops[0])
+    assert m0_users <= {'s_mov_b32'}, m0_users
+    assert 'global_load_lds_dwordx4' in text
