@@ -1,7 +1,8 @@
 """Same-box A/B of kernel micro-benchmarks between library builds (BP_HIP_LIB selects the build per subprocess).
 
     python scripts/ab_kernels.py --libs default,r3k --which mix,bwd,mixbwd --batch 64 [--reps 3] [--out FILE.jsonl]
-`default` = bp_hip/libbackpack_hip.so, any other name N = bp_hip/libbackpack_hip_N.so (build_hip.py --variant N).
+`default` = bp_hip/libbackpack_hip.so, any other name N = bp_hip/libbackpack_hip_N.so (build_hip.py --variant N);
+`N+VAR=VALUE` runs build N with that environment variable set (run-time switches of one build).
 The builds run interleaved, `reps` times each, so clock / thermal drift hits them alike; one JSON line per run."""
 import argparse
 import json
@@ -28,6 +29,10 @@ def main():
     for rep in range(a.reps):
         for name in libs:
             env = dict(os.environ)
+            name, *settings = name.split('+')      # `lib+VAR=VALUE+...`: the build plus environment switches
+            for kv in settings:
+                k, v = kv.split('=', 1)
+                env[k] = v
             if name != 'default':
                 env['BP_HIP_LIB'] = os.path.join(ROOT, 'backpacks-flash-attn_amd', 'bp_hip', 'libbackpack_hip_%s.so' % name)
             else:
@@ -42,7 +47,7 @@ def main():
                 for line in r.stdout.splitlines():
                     if line.startswith('{'):
                         row = json.loads(line)
-                        row.update(lib=name, rep=rep)
+                        row.update(lib='+'.join([name] + settings), rep=rep)
                         rows.append(row)
                         print(json.dumps(row), flush=True)
     # summary: best (min) time per (lib, kernel, batch)

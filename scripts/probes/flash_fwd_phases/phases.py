@@ -42,7 +42,7 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); run(); e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
-    buf = np.zeros((8192, 4, 12), dtype=np.uint64)
+    buf = np.zeros((8192, 4, 16), dtype=np.uint64)   # (12 slots before round 4, run r)
     assert lib.bp_dev_fwd_prof(buf.ctypes.data_as(ctypes.c_void_p), 0) == 0
     p = buf.astype(np.float64)
     fast, passes = p[:, :, 6].sum(), p[:, :, 10].sum()
@@ -61,6 +61,16 @@ def main():
     res['per pass: prologue'] = round(p[:, :, 8].sum() / passes, 1)
     res['per pass: epilogue'] = round(p[:, :, 9].sum() / passes, 1)
     del res['wait+barrier per ring step'], res['DMA issue per ring step']
+    # round 4: lifetime of a workgroup (kernel entry -> exit of wave 0), in shader clocks and in 10-ns real-time ticks
+    life_c, life_r = p[:, 0, 11], p[:, 0, 12]
+    alive = life_r > 0
+    if alive.any():
+        res['workgroups recorded'] = int(alive.sum())
+        res['workgroup lifetime us'] = round(life_r[alive].mean() * 0.01, 2)
+        res['shader clock GHz'] = round(life_c[alive].sum() / (life_r[alive].sum() * 10.0), 3)
+        res['passes per workgroup'] = round(p[alive][:, 0, 10].sum() / alive.sum(), 2)
+        res['pass clocks / lifetime clocks (wave 0)'] = round(p[alive][:, 0, 7].sum() / life_c[alive].sum(), 4)
+        res['sum of lifetimes / kernel time (= resident workgroups, chip)'] = round(life_r[alive].sum() * 0.01 / (ms * 1000.0), 1)
     print(json.dumps(res))
 
 
