@@ -259,6 +259,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-threads', type=int, default=None)
     ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--no-content-dedup', action='store_true',
+                    help='run the content (sense) network on every position, as the reference does, instead of once per '
+                         'distinct token of the batch (src/models/backpack.py: BackpackModel._dedup_applies)')
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
                     help="'nccl' (= RCCL, one rank per GPU) for every real run; 'gloo' moves the same collectives "
                          "through host memory and lets several ranks share one GPU -- the test-suite's world-size-2 run "
@@ -293,6 +296,8 @@ def main():
     model_name, seq, dtype_name, default_batch = WORKLOADS[args.workload]
     dtype = torch.bfloat16 if dtype_name == 'bf16' else torch.float16
     cfg, model = build_model(model_name, seq, dtype, device)
+    if args.no_content_dedup:
+        model.transformer.dedup_content = False
 
     def make_ids(b):
         return torch.randint(0, 50257, (b, seq), device=device,
@@ -386,6 +391,41 @@ def main():
     clock.enabled = False
     assert out.shape == (batch, seq, cfg.vocab_size) and bool(torch.isfinite(out[0, -1].float()).all())
 
+    # The same step with the content network run on every POSITION (the reference's order of operations), timed next to
+    # the headline so that both numbers come from one process on one box: a few steps, same batch, same barriers.
+    with torch.no_grad():
+        dedup_on = bool(model.transformer._dedup_applies(ids))
+    per_position = None
+    if dedup_on and not args.graph:
+        model.transformer.dedup_content = False
+        n_pp = max(1, min(args.steps, 3))
+        try:
+            out = None
+            step()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(n_pp):
+                out = step()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            el_pp = time.perf_counter() - t1
+            if dist is not None:
+                t = torch.tensor([el_pp], device=device, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el_pp = float(t.item())
+            per_position = dict(value=round(world * batch * seq * n_pp / el_pp, 1), unit='tokens/s', steps=n_pp,
+                                ms_per_step=round(el_pp / n_pp * 1e3, 3))
+        except torch.OutOfMemoryError:
+            # (the per-position content tensor is 25 MB per sample more than the deduplicated path needs)
+            per_position = dict(value=None, note='out of HBM at this batch with the content network run per position')
+            if dist is not None:
+                raise
+        model.transformer.dedup_content = True
+        out = None
+
     if dist is not None:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -429,8 +469,12 @@ def main():
                        'batch_per_gpu': batch, 'global_batch': batch * world, 'seq_len': seq,
                        'batch_choice': 'auto: largest batch within 1 % of the best rate in batch_sweep (candidates up to 90 % of HBM; logits in one persistent block)' if sweep else 'given',
                        'hbm_frac_peak': round(torch.cuda.max_memory_allocated(device) / torch.cuda.get_device_properties(device).total_memory, 3),
+                       'content_network': ('once per distinct token id of the batch (torch.unique + row gather; exact: the '
+                                           'sense vectors depend on the token alone)' if dedup_on else 'once per position'),
                        'parallelism': f'{world} independent batch replicas (no data-path collective)'},
         }
+        if per_position is not None:
+            line['content_per_position'] = per_position   # the reference's order of operations, same process / batch
         if kernel_rows:
             # `roofline` = the attention-path kernel with the largest total time (the path BASELINE.json's
             # north_star names: flash attention tile / sense contraction); every timed kernel, including the

@@ -51,6 +51,49 @@ def test_nano_model_hip_vs_golden(fused):
     assert torch.count_nonzero(alpha[:, :, upper]) == 0
 
 
+def test_content_dedup_matches_the_per_position_content_network():
+    """Inference forward with the content network run once per distinct token (default) against the same model with
+    `dedup_content` off (the reference's order: every position): same hidden states and logits to bf16 GEMM noise, the
+    switch conditions honoured (taken for >= 2 x vocab positions under no_grad in eval; not in training, not with
+    autograd, not for small inputs)."""
+    g, sd, model = _nano(fused=True)
+    t = model.transformer
+    ids = torch.randint(0, 96, (8, 32), device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    calls = []
+    orig = t._content_of_unique_tokens
+    t._content_of_unique_tokens = lambda x: (calls.append(x.shape), orig(x))[1]
+    with torch.no_grad():
+        assert t._dedup_applies(ids) and not t._dedup_applies(ids[:2])        # 256 >= 192 positions; 64 < 192
+        hid = t(ids)
+        logits = model(ids).logits
+        assert len(calls) == 2
+        t.dedup_content = False
+        assert not t._dedup_applies(ids)
+        hid_pp = t(ids)
+        logits_pp = model(ids).logits
+        assert len(calls) == 2
+        t.dedup_content = True
+    assert not t._dedup_applies(ids)                                          # autograd enabled
+    model.train()
+    with torch.no_grad():
+        assert not t._dedup_applies(ids)                                      # dropout would differ per position
+    model.eval()
+    # identical inputs to the mix kernel up to the row-count dependence of the BLAS GEMMs: compare at bf16 resolution
+    assert (hid.float() - hid_pp.float()).abs().max().item() <= 2 ** -7 * hid_pp.float().abs().max().item()
+    assert (logits.float() - logits_pp.float()).abs().max().item() <= 2 ** -6 * logits_pp.float().abs().max().item()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.stream(side):
+        t(ids)
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.no_grad(), torch.cuda.graph(graph):
+        hid_g = t(ids)                                                        # capture: the per-position path, no unique()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert len(calls) == 3 and torch.equal(hid_g, hid_pp)
+
+
 def test_fused_path_equals_materialised_alpha_path():
     """BackpackModel.forward (fused, alpha never stored) vs alpha from ContextSelfAttn @ content."""
     g, sd, model = _nano()

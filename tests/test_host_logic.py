@@ -413,3 +413,25 @@ def test_lm_head_writes_into_a_caller_owned_logits_buffer():
         model(ids, logits_out=buf[:2])
     with torch.no_grad(), pytest.raises(RuntimeError, match='logits_out must be'):
         model(ids, logits_out=torch.empty(2, 16, 95))
+
+
+def test_content_of_unique_tokens_equals_the_per_position_content():
+    """Inference on the HIP path runs the content (sense) network once per DISTINCT token of the batch and gathers the
+    rows (BackpackModel._content_of_unique_tokens): the sense vectors are a function of the token alone (reference
+    backpack.py:251-276: no positions, Identity mixer).  On the CPU, in fp32, the gathered tensor equals the
+    per-position one; the switch itself is taken only where it is exact and pays (GPU, eval, no autograd, no capture,
+    >= 2 x vocabulary positions)."""
+    torch.manual_seed(0)
+    model = BackpackLMHeadModel(nano_config()).eval()
+    t = model.transformer
+    ids = torch.randint(0, 96, (4, 64))
+    with torch.no_grad():
+        want = t.content_model(ids)
+        got = t._content_of_unique_tokens(ids)
+    assert got.shape == want.shape == (4, 4, 64, 64)
+    assert torch.allclose(got, want, atol=1e-6, rtol=0)
+    assert got.transpose(1, 2).is_contiguous()             # the (B,S,k,d) storage the mix kernel consumes as it lies
+    assert t.dedup_content is True
+    with torch.no_grad():
+        assert not t._dedup_applies(ids)                   # CPU tensors: the eager path stays the reference's, literally
+    assert BackpackLMHeadModel(nano_config(dedup_content=False)).transformer.dedup_content is False
