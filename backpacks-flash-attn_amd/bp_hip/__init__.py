@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('BP_HIP_LIB') or os.path.join(_HERE, 'libbackpack_hip.so')  # env: A/B builds only
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 
@@ -60,6 +60,7 @@ SIGNATURES = {
     'bp_sense_alpha': (_i32, [_ptr] * 3 + [_i32] * 5 + [_i64] * 4 + [_f32, _i32, _ptr]),
     'bp_sense_mix': (_i32, [_ptr] * 4 + [_i32] * 6 + [_i64] * 9 + [_f32, _i32, _ptr, _ptr]),
     'bp_sense_mix_weighted': (_i32, [_ptr] * 5 + [_i32] * 6 + [_i64] * 11 + [_f32, _i32, _ptr, _ptr]),
+    'bp_sense_mix_gather': (_i32, [_ptr] * 5 + [_i32] * 6 + [_i64] * 10 + [_f32, _i32, _ptr, _ptr]),
     'bp_sense_mix_dc': (_i32, [_ptr] * 4 + [_i32] * 5 + [_i64] * 9 + [_f32, _i32, _ptr, _ptr]),
     'bp_sense_dq_dk': (_i32, [_ptr] * 6 + [_i32] * 5 + [_i64] * 11 + [_f32, _i32, _ptr]),
     'bp_add_layer_norm': (_i32, [_ptr] * 6 + [_i64, _i32, _f32] + [_i32] * 4 + [_ptr]),
@@ -420,6 +421,50 @@ def sense_mix(qk, content, softmax_scale=None, out=None, lse=None, key_weight=No
             out.stride(0), out.stride(1), float(scale), _dtype_code(qk), queue_ws.data_ptr(), _stream())
     del queue_ws
     _check(code, 'bp_sense_mix_weighted')
+    return out
+
+
+def sense_mix_gather_supported(qk, table, seqlen):
+    """Shapes bp_sense_mix_gather takes (include/bp_hip.h): the 16-byte vector path, seqlen <= 4096 (2048 for d_k > 64),
+    32-bit row offsets into the table."""
+    dk = round_up(qk.shape[-1], 8)
+    return (qk.is_cuda and table.is_cuda and table.dim() == 3 and table.stride(-1) == 1 and table.shape[2] % 8 == 0
+            and table.stride(0) % 8 == 0 and table.stride(1) % 8 == 0 and table.data_ptr() % 16 == 0
+            and seqlen <= (4096 if dk <= 64 else 2048)
+            and table.shape[0] * table.stride(0) * table.element_size() < 2 ** 32)
+
+
+def sense_mix_gather(qk, table, row_index, softmax_scale=None, out=None, lse=None):
+    """sense_mix with the content rows read from a table: content[b, s, l, :] = table[row_index[b, s], l, :].
+
+    qk (B,S,2,k,d_k); table (rows, k, d_out), e.g. the content network's output for the distinct tokens of the batch;
+    row_index (B,S) int32 (torch.unique's inverse); returns (B,S,d_out).  The (B,S,k,d_out) content tensor of
+    backpack.py:276 is never materialised (C ABI bp_sense_mix_gather)."""
+    b, s, k, dk = _check_qk(qk)
+    _require_cuda(table, row_index)
+    if table.dim() != 3 or table.shape[1] != k or table.stride(-1) != 1:
+        raise RuntimeError('bp_hip.sense_mix_gather: table must be (rows, k, d_out), last dim contiguous')
+    if table.dtype != qk.dtype:
+        raise RuntimeError('bp_hip.sense_mix_gather: qk and table dtypes differ')
+    if row_index.shape != (b, s) or row_index.dtype != torch.int32 or row_index.stride(-1) != 1:
+        raise RuntimeError('bp_hip.sense_mix_gather: row_index must be (B, S) int32, unit stride along S')
+    dout = table.shape[2]
+    scale = softmax_scale or dk ** -0.5
+    qk, _ = _vector_friendly_qk(qk)
+    dk = qk.shape[-1]
+    if out is None:
+        out = torch.empty((b, s, dout), dtype=qk.dtype, device=qk.device)
+    ws, ready = _lse_ws(qk, lse, b, s, k)
+    queue_ws = _queue_ws(qk.device)   # alive until the launch call has returned
+    with torch.cuda.device(qk.device):
+        code = lib().bp_sense_mix_gather(
+            qk.data_ptr(), table.data_ptr(), row_index.data_ptr(), out.data_ptr(), ws.data_ptr(), ready,
+            b, s, k, dk, dout, table.shape[0],
+            qk.stride(0), qk.stride(1), qk.stride(2), qk.stride(3),
+            table.stride(0), table.stride(1), row_index.stride(0),
+            out.stride(0), out.stride(1), float(scale), _dtype_code(qk), queue_ws.data_ptr(), _stream())
+    del queue_ws
+    _check(code, 'bp_sense_mix_gather')
     return out
 
 

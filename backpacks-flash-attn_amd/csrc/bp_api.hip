@@ -325,6 +325,50 @@ int bp_sense_mix_weighted(const void *qk, const void *content, const float *key_
     return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
 }
 
+int bp_sense_mix_gather(const void *qk, const void *table, const int32_t *row_index, void *out,
+                        float *lse_ws, int lse_ready,
+                        int batch, int seqlen, int nsenses, int d_k, int d_out, int64_t table_rows,
+                        int64_t qk_batch_stride, int64_t qk_row_stride, int64_t qk_two_stride,
+                        int64_t qk_sense_stride,
+                        int64_t t_row_stride, int64_t t_sense_stride, int64_t idx_batch_stride,
+                        int64_t o_batch_stride, int64_t o_row_stride,
+                        float softmax_scale, int dtype, void *queue_ws, bp_stream_t stream) {
+    if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
+    if (d_k < 8 || d_k > 128 || d_k % 8 != 0) return BP_ERR_HEAD_DIM;
+    if (queue_ws != nullptr && !aligned16(queue_ws)) return BP_ERR_SHAPE;
+    if (d_out < 8 || d_out % 8 != 0) return BP_ERR_DOUT;
+    if (batch <= 0 || nsenses <= 0 || seqlen <= 0 || seqlen > bp::mix_gather_max_keys(d_k) || table_rows <= 0) return BP_ERR_SHAPE;
+    if (qk == nullptr || table == nullptr || row_index == nullptr || out == nullptr || lse_ws == nullptr) return BP_ERR_SHAPE;
+    if (!scale_ok(softmax_scale)) return BP_ERR_SCALE;
+    const uint16_t *qp = static_cast<const uint16_t *>(qk);
+    if (!aligned16(qp) || !aligned16(qp + qk_two_stride) || !aligned16(table) || !aligned16(out)) return BP_ERR_SHAPE;
+    const int64_t strides[] = {qk_batch_stride, qk_row_stride, qk_sense_stride, t_row_stride, t_sense_stride,
+                               o_batch_stride, o_row_stride};
+    for (int64_t v : strides) if (!mult8(v)) return BP_ERR_SHAPE;
+    if (t_row_stride <= 0 || table_rows * t_row_stride * 2 >= (int64_t(1) << 32)) return BP_ERR_SHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (null_queue_ws_on_capturing_stream(queue_ws, st)) return BP_ERR_QUEUE_WS;
+    if (!lse_ready) {
+        int rc = sense_lse(qk, lse_ws, batch, seqlen, nsenses, d_k, qk_batch_stride, qk_row_stride,
+                           qk_two_stride, qk_sense_stride, softmax_scale, dtype, st);
+        if (rc != BP_OK) return rc;
+    }
+    bp::MixParams p{};
+    p.q = qp; p.k = qp + qk_two_stride; p.c = table; p.o = out; p.lse = lse_ws;
+    p.row_index = row_index; p.idx_bs = idx_batch_stride;
+    p.qk_bs = qk_batch_stride; p.qk_rs = qk_row_stride; p.qk_ss = qk_sense_stride;
+    p.c_bs = 0; p.c_rs = t_row_stride; p.c_ss = t_sense_stride;
+    p.o_bs = o_batch_stride; p.o_rs = o_row_stride;
+    p.lse_stride = round_up(seqlen, 16);
+    p.b = batch; p.s = seqlen; p.nsenses = nsenses; p.dk = d_k; p.dout = d_out;
+    p.n_qtiles = (seqlen + 255) / 256;
+    p.n_chunks = (d_out + 255) / 256;
+    p.scale_log2e = softmax_scale * bp::kLog2e;
+    p.queues = static_cast<bp::MixQueues *>(queue_ws);
+    const hipError_t e = bp::launch_sense_mix_dma(p, dtype, st);
+    return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
+}
+
 int bp_sense_mix_dc(const void *qk, const void *dout, const float *lse, void *dcontent,
                     int batch, int seqlen, int nsenses, int d_k, int d_out,
                     int64_t qk_batch_stride, int64_t qk_row_stride, int64_t qk_two_stride, int64_t qk_sense_stride,

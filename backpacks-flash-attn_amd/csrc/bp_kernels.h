@@ -76,6 +76,8 @@ struct MixParams {
     const float *lse;         // (b, k, lse_stride) natural-log LSE of every (sense, query)
     const float *kw;          // optional key weights w[b, l, s] (fp32, unit stride along s): alpha[b,l,:,s] *= w
     int64_t kw_bs, kw_ss;
+    const int32_t *row_index; // optional (bp_sense_mix_gather): content[b, s, l, :] = c + row_index[b*idx_bs + s]*c_rs + l*c_ss
+    int64_t idx_bs;
     int64_t qk_bs, qk_rs, qk_ss;
     int64_t c_bs, c_rs, c_ss;
     int64_t o_bs, o_rs;
@@ -86,6 +88,9 @@ struct MixParams {
     float scale_log2e;
     MixQueues *queues;        // caller's record (queue_ws) or NULL; armed by launch_sense_mix_dma
 };
+
+// longest sequence the gathering sense mix takes: its per-job offset table shares the LDS with the ring (sense_mix_dma.hip)
+inline int mix_gather_max_keys(int d_k) { return d_k <= 64 ? 4096 : 2048; }
 
 // backward of the sense combination (sense_mix_bwd.hip)
 struct MixBwdParams {

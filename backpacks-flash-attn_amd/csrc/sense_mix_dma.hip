@@ -68,13 +68,18 @@ struct MixDmaCfg {
     static constexpr int K_ROWS_PER_DMA = 1024 / KROW;   // 8 or 4
     static constexpr int JOB_OFF = NSTAGE * STAGE;       // 16 bytes: job broadcast
     static constexpr int SMEM = JOB_OFF + 16;
+    // GATHER (bp_sense_mix_gather): the content rows are rows of a TABLE (one per distinct token of the batch), picked by
+    // an index per key.  The job's byte offsets index[key] * row bytes live behind the ring, one u32 per key.
+    static constexpr int GATHER_OFF = SMEM;
+    static constexpr int GATHER_MAX_KEYS = KD <= 4 ? 4096 : 2048;   // (= mix_gather_max_keys(d_k), bp_kernels.h: 160 KB of LDS)
+    static constexpr int GATHER_BYTES = GATHER_MAX_KEYS * 4;
 };
 
-template <class ET, int KD, bool FULL, bool WEIGHTED>
+template <class ET, int KD, bool FULL, bool WEIGHTED, bool GATHER = false>
 __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
     using C = MixDmaCfg<KD, WEIGHTED>;
     using E = Elem<ET>;
-    __shared__ __attribute__((aligned(16))) char smem[C::SMEM];
+    __shared__ __attribute__((aligned(16))) char smem[C::SMEM + (GATHER ? C::GATHER_BYTES : 0)];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
 
         const uint16_t *qg = reinterpret_cast<const uint16_t *>(p.q) + batch * p.qk_bs;
         const uint16_t *kg = reinterpret_cast<const uint16_t *>(p.k) + batch * p.qk_bs;
-        const uint16_t *cg = reinterpret_cast<const uint16_t *>(p.c) + batch * p.c_bs;
+        const uint16_t *cg = reinterpret_cast<const uint16_t *>(p.c) + (GATHER ? 0 : batch * p.c_bs);
 
         const int k_end = min(S, qt * C::BM + C::BM);
         const int nkb = (k_end + C::BK - 1) / C::BK;
@@ -184,7 +189,16 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
             const int stored = lane_o & 31;
             const int logical = (((stored >> 2) ^ (row & 3)) << 2) | (stored & 3);
             const int col = (FULL || col_base + logical * 8 < p.dout) ? col_base + logical * 8 : col_base;
-            c_voff[j] = (uint32_t)(row * p.c_rs + col) * 2u;
+            c_voff[j] = (uint32_t)((GATHER ? 0 : row * p.c_rs) + col) * 2u;   // (GATHER: the row part comes from the table)
+        }
+        if (GATHER) {
+            // byte offset of every key's table row, clamped past the sequence end (those keys are masked); every wave is
+            // done with the previous job's table (the __syncthreads in front of the job word)
+            const int32_t *idx = p.row_index + (int64_t)batch * p.idx_bs;
+            const uint32_t row_bytes = (uint32_t)p.c_rs * 2u;
+            for (int i = tid; i < nkb * C::BK; i += C::NT)
+                *reinterpret_cast<uint32_t *>(smem + C::GATHER_OFF + i * 4) = (uint32_t)idx[min(i, S - 1)] * row_bytes;
+            __syncthreads();
         }
 
         // DMA pieces of the tile two steps ahead, (l2, kb2), into ring slot `slot`; `pieces` selects a subset (bit j).
@@ -194,6 +208,13 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
         const uint16_t *ks2 = kg, *cs2 = cg;     // key / content base of sense l2
         const uint16_t *kt2 = kg, *ct2 = cg;     // ... of tile kb2 in it
         const int64_t k_tile_step = (int64_t)C::BK * p.qk_rs, c_tile_step = (int64_t)C::BK * p.c_rs;
+        // GATHER: piece j of tile kb2 = two table rows, their byte offsets read from the job's LDS table; the base is the
+        // SENSE's (table + l2 * c_ss), and table rows are re-read by other jobs, so the loads stay cacheable
+        auto gather_piece = [&](int j, uint32_t lds_dst) {
+            const int key = kb2 * C::BK + c_piece_row(j);
+            const uint32_t off = *reinterpret_cast<const uint32_t *>(smem + C::GATHER_OFF + key * 4) + c_voff[j];
+            dma16_s(cs2, off, lds_dst);
+        };
         auto issue = [&](int, int, int slot, uint32_t pieces) {
             const uint32_t stage_off = lds0 + slot * C::STAGE;
             if (__builtin_expect(kb2 == kb_partial, 0)) {
@@ -206,6 +227,10 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
 #pragma unroll
                 for (int j = 0; j < C::C_DMA; ++j)
                     if ((pieces >> (C::K_DMA + j)) & 1u) {
+                        if (GATHER) {
+                            gather_piece(j, __builtin_amdgcn_readfirstlane(stage_off + C::KTILE + (wave * C::C_DMA + j) * 1024));
+                            continue;
+                        }
                         const uint32_t back = (uint32_t)(max(c_piece_row(j) - last_row, 0) * p.c_rs) * 2u;
                         dma16_s_nt(ct2, c_voff[j] - back,
                                    __builtin_amdgcn_readfirstlane(stage_off + C::KTILE + (wave * C::C_DMA + j) * 1024));
@@ -216,9 +241,11 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
                     if ((pieces >> j) & 1u) dma16_s(kt2, k_voff[j], stage_off + (wave * C::K_DMA + j) * 1024);
 #pragma unroll
                 for (int j = 0; j < C::C_DMA; ++j)
-                    if ((pieces >> (C::K_DMA + j)) & 1u)
+                    if ((pieces >> (C::K_DMA + j)) & 1u) {
+                        if (GATHER) gather_piece(j, stage_off + C::KTILE + (wave * C::C_DMA + j) * 1024);
                         // the content stream is read once per job: non-temporal (-1.6 % at B=64, r02_p)
-                        dma16_s_nt(ct2, c_voff[j], stage_off + C::KTILE + (wave * C::C_DMA + j) * 1024);
+                        else dma16_s_nt(ct2, c_voff[j], stage_off + C::KTILE + (wave * C::C_DMA + j) * 1024);
+                    }
             }
             if (WEIGHTED && ((pieces >> (C::K_DMA + C::C_DMA)) & 1u)) {
                 // key weights of this (sense, tile): lane i fetches w[key0 + i] into the wave's own 256-B slot
@@ -596,7 +623,10 @@ static hipError_t launch_kd(MixParams p, hipStream_t stream) {
     const int njobs = p.b * p.n_chunks * p.n_qtiles;
     const int cus = mix_persistent_grid();
     dim3 g(njobs < cus ? njobs : cus), t(512);   // 120 KB of LDS: one workgroup per CU
-    if (p.kw != nullptr) {
+    if (p.row_index != nullptr) {   // (bp_api.hip: never together with key weights; seqlen <= GATHER_MAX_KEYS)
+        if (p.dout % 256 == 0) hipLaunchKernelGGL((sense_mix_dma_kernel<ET, KD, true, false, true>), g, t, 0, stream, p);
+        else hipLaunchKernelGGL((sense_mix_dma_kernel<ET, KD, false, false, true>), g, t, 0, stream, p);
+    } else if (p.kw != nullptr) {
         if (p.dout % 256 == 0) hipLaunchKernelGGL((sense_mix_dma_kernel<ET, KD, true, true>), g, t, 0, stream, p);
         else hipLaunchKernelGGL((sense_mix_dma_kernel<ET, KD, false, true>), g, t, 0, stream, p);
     } else if (p.dout % 256 == 0) hipLaunchKernelGGL((sense_mix_dma_kernel<ET, KD, true, false>), g, t, 0, stream, p);

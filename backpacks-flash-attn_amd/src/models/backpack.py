@@ -256,19 +256,29 @@ class BackpackModel(GPTPreTrainedModel):
                 and input_ids.is_cuda and input_ids.numel() >= 2 * self.embeddings.word_embeddings.weight.shape[0]
                 and not torch.cuda.is_current_stream_capturing())
 
-    def _content_of_unique_tokens(self, input_ids):
+    def _table_of_unique_tokens(self, input_ids):
+        """(rows (U, k, d) = the content network's output for the sorted distinct ids, index (B, S) of every position's row)"""
         uniq, inverse = torch.unique(input_ids, return_inverse=True)
         table = self.content_model(uniq.unsqueeze(0))                  # (1,k,U,d) view of one (1,U,k*d) block
-        k, d = table.shape[1], table.shape[3]
-        rows = table.transpose(1, 2).reshape(uniq.numel(), k * d)       # (no copy: the block as it lies)
-        content = torch.nn.functional.embedding(inverse, rows)          # (B,S,k*d): every position's row of the table
+        return table[0].transpose(0, 1), inverse                        # (U,k,d): the block as it lies, no copy
+
+    def _content_of_unique_tokens(self, input_ids):
+        rows, inverse = self._table_of_unique_tokens(input_ids)
+        u, k, d = rows.shape
+        content = torch.nn.functional.embedding(inverse, rows.reshape(u, k * d))   # (B,S,k*d): every position's row
         return content.view(*input_ids.shape, k, d).transpose(1, 2)    # (B,k,S,d) view, as content_model returns it
 
     def forward(self, input_ids, position_ids=None, inference_params=None):
         contextl_hidden_states = self.gpt2_model(input_ids, position_ids=position_ids,
                                                  inference_params=inference_params)
         if self._dedup_applies(input_ids):
-            content = self._content_of_unique_tokens(input_ids)
+            rows, inverse = self._table_of_unique_tokens(input_ids)
+            qk = self.contextualization_attn.project(contextl_hidden_states)
+            if bp_hip.sense_mix_gather_supported(qk, rows, input_ids.shape[1]):
+                # the mix kernel reads the table rows itself: no (B,S,k,d) content tensor at all
+                return bp_hip.sense_mix_gather(qk, rows, inverse.to(torch.int32), self.contextualization_attn.scale())
+            content = torch.nn.functional.embedding(inverse, rows.reshape(rows.shape[0], -1))
+            return bp_hip.sense_mix(qk, content.view(*input_ids.shape, *rows.shape[1:]), self.contextualization_attn.scale())
         else:
             content = self.content_model(input_ids, position_ids, inference_params)   # (B,k,S,d) view
         if self.use_hip:

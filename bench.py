@@ -93,8 +93,17 @@ def instrument(clock):
             lse = t_lse(qk, softmax_scale)
         return t_mix(qk, content, softmax_scale, out=out, lse=lse, key_weight=key_weight)
 
+    raw_gather = bp_hip.sense_mix_gather
+    t_gather = clock.wrap('sense_mix_kernel', raw_gather)
+
+    def gather_two_launches(qk, table, row_index, softmax_scale=None, out=None, lse=None):
+        if lse is None:
+            lse = t_lse(qk, softmax_scale)
+        return t_gather(qk, table, row_index, softmax_scale, out=out, lse=lse)
+
     bp_hip.flash_fwd = t_flash
     bp_hip.sense_mix = mix_two_launches
+    bp_hip.sense_mix_gather = gather_two_launches
     bp_hip.add_layer_norm = clock.wrap('add_layer_norm_kernel', bp_hip.add_layer_norm)
 
 
@@ -393,38 +402,51 @@ def main():
 
     # The same step with the content network run on every POSITION (the reference's order of operations), timed next to
     # the headline so that both numbers come from one process on one box: a few steps, same batch, same barriers.
+    hbm_peak = torch.cuda.max_memory_allocated(device)
     with torch.no_grad():
         dedup_on = bool(model.transformer._dedup_applies(ids))
     per_position = None
     if dedup_on and not args.graph:
         model.transformer.dedup_content = False
         n_pp = max(1, min(args.steps, 3))
-        try:
-            out = None
-            step()
-            torch.cuda.synchronize()
+        out = None
+        b_pp = batch   # the per-position content tensor needs 25 MB per sample more: step down if the batch does not fit
+        while per_position is None:
+            failed = 0
+            try:
+                with torch.no_grad():
+                    model(ids[:b_pp], logits_out=logits_out[:b_pp])
+                torch.cuda.synchronize()
+                if dist is not None:
+                    dist.barrier()
+                t1 = time.perf_counter()
+                with torch.no_grad():
+                    for _ in range(n_pp):
+                        model(ids[:b_pp], logits_out=logits_out[:b_pp])
+                torch.cuda.synchronize()
+                if dist is not None:
+                    dist.barrier()
+                el_pp = time.perf_counter() - t1
+            except torch.OutOfMemoryError:
+                failed = 1
             if dist is not None:
-                dist.barrier()
-            t1 = time.perf_counter()
-            for _ in range(n_pp):
-                out = step()
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-            el_pp = time.perf_counter() - t1
+                t = torch.tensor([failed], device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                failed = int(t.item())
+            if failed:
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+                b_pp = b_pp * 3 // 4
+                if b_pp < 1:
+                    per_position = dict(value=None, note='out of HBM with the content network run per position')
+                continue
             if dist is not None:
                 t = torch.tensor([el_pp], device=device, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 el_pp = float(t.item())
-            per_position = dict(value=round(world * batch * seq * n_pp / el_pp, 1), unit='tokens/s', steps=n_pp,
-                                ms_per_step=round(el_pp / n_pp * 1e3, 3))
-        except torch.OutOfMemoryError:
-            # (the per-position content tensor is 25 MB per sample more than the deduplicated path needs)
-            per_position = dict(value=None, note='out of HBM at this batch with the content network run per position')
-            if dist is not None:
-                raise
+            per_position = dict(value=round(world * b_pp * seq * n_pp / el_pp, 1), unit='tokens/s', steps=n_pp,
+                                ms_per_step=round(el_pp / n_pp * 1e3, 3), batch_per_gpu=b_pp)
         model.transformer.dedup_content = True
-        out = None
 
     if dist is not None:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -468,8 +490,8 @@ def main():
                                    f'senses, vocab {cfg.vocab_size}, seq {seq}',
                        'batch_per_gpu': batch, 'global_batch': batch * world, 'seq_len': seq,
                        'batch_choice': 'auto: largest batch within 1 % of the best rate in batch_sweep (candidates up to 90 % of HBM; logits in one persistent block)' if sweep else 'given',
-                       'hbm_frac_peak': round(torch.cuda.max_memory_allocated(device) / torch.cuda.get_device_properties(device).total_memory, 3),
-                       'content_network': ('once per distinct token id of the batch (torch.unique + row gather; exact: the '
+                       'hbm_frac_peak': round(hbm_peak / torch.cuda.get_device_properties(device).total_memory, 3),
+                       'content_network': ('once per distinct token id of the batch (torch.unique; the mix kernel gathers the rows; exact: the '
                                            'sense vectors depend on the token alone)' if dedup_on else 'once per position'),
                        'parallelism': f'{world} independent batch replicas (no data-path collective)'},
         }

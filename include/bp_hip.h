@@ -28,11 +28,11 @@
 extern "C" {
 #endif
 
-#define BP_ABI_VERSION 5   /* 2: *_dropout entry points added; 3: bias/GELU + column-sum entry points added, the
+#define BP_ABI_VERSION 6   /* 2: *_dropout entry points added; 3: bias/GELU + column-sum entry points added, the
                               persistent sense-mix launches take a caller-owned `queue_ws`; 4: bp_flash_bwd* take the
                               size of `dsum_ws` (bp_flash_bwd_ws_floats) and check it, queue_ws == NULL is refused
                               while the stream is capturing (BP_ERR_QUEUE_WS); 5: bp_dropout_add_layer_norm_scaled{,_bwd}
-                              (rowscale / colscale of the reference's dropout_add_ln) added */
+                              (rowscale / colscale of the reference's dropout_add_ln) added; 6: bp_sense_mix_gather added */
 
 /* element type of q/k/v/out/content tensors */
 #define BP_DTYPE_F16 0
@@ -213,6 +213,30 @@ int bp_sense_mix_weighted(const void *qk, const void *content, const float *key_
                           int64_t kw_batch_stride, int64_t kw_sense_stride,
                           int64_t o_batch_stride, int64_t o_row_stride,
                           float softmax_scale, int dtype, void *queue_ws, bp_stream_t stream);
+
+/*
+ * bp_sense_mix_gather -- bp_sense_mix with the content rows taken from a TABLE through a row index:
+ *   out[b,t,:] = sum_l sum_{s<=t} alpha[b,l,t,s] * table[row_index[b,s], l, :]
+ * The sense vectors C_l(x_s) of the reference depend on the token x_s alone (training/src/models/backpack.py:251-276: word
+ * embedding without positions, an Identity mixer, per-token MLPs), so inference can run the content network once per
+ * DISTINCT token of a batch (table = its output for the sorted distinct ids, row_index = torch.unique's inverse) and never
+ * materialise the (batch, seqlen, nsenses * d_out) content tensor the reference builds (:276, :313).
+ *   table      (table_rows, nsenses, d_out), element strides t_row_stride / t_sense_stride, last dim contiguous
+ *   row_index  (batch, seqlen) int32, unit stride along seqlen, element stride idx_batch_stride; 0 <= value < table_rows
+ *              (not checked on the device: an index outside the table reads outside the table)
+ * Restrictions (BP_ERR_SHAPE otherwise; callers gather the rows themselves and call bp_sense_mix): the 16-byte vector
+ * path (d_k % 8 == 0, d_out % 8 == 0, aligned bases, strides multiples of 8), seqlen <= 4096 (2048 for d_k > 64), and
+ * table_rows * t_row_stride * 2 bytes < 4 GiB (row offsets are 32-bit in the DMA instruction).
+ * All other arguments as bp_sense_mix.
+ */
+int bp_sense_mix_gather(const void *qk, const void *table, const int32_t *row_index, void *out,
+                        float *lse_ws, int lse_ready,
+                        int batch, int seqlen, int nsenses, int d_k, int d_out, int64_t table_rows,
+                        int64_t qk_batch_stride, int64_t qk_row_stride, int64_t qk_two_stride,
+                        int64_t qk_sense_stride,
+                        int64_t t_row_stride, int64_t t_sense_stride, int64_t idx_batch_stride,
+                        int64_t o_batch_stride, int64_t o_row_stride,
+                        float softmax_scale, int dtype, void *queue_ws, bp_stream_t stream);
 
 /*
  * bp_sense_mix_dc -- backward of bp_sense_mix with respect to the content:

@@ -23,9 +23,11 @@ HOT = [
     ('flash_fwd_dma.o', 'flash_fwd_dma_kernel<BF16, 5, 3, true, false, false>', 3),
     ('flash_fwd_dma.o', 'flash_fwd_dma_kernel<BF16, 1, 1, false, false, false>', 4),
     # fused sense mix: Small (d_k = 48) and Mini (16), 768 / 640 output columns
-    ('sense_mix_dma.o', 'sense_mix_dma_kernel<BF16, 3, true, false>', 2),
-    ('sense_mix_dma.o', 'sense_mix_dma_kernel<F16, 3, true, false>', 2),
-    ('sense_mix_dma.o', 'sense_mix_dma_kernel<BF16, 1, false, false>', 2),
+    ('sense_mix_dma.o', 'sense_mix_dma_kernel<BF16, 3, true, false, false>', 2),
+    ('sense_mix_dma.o', 'sense_mix_dma_kernel<F16, 3, true, false, false>', 2),
+    ('sense_mix_dma.o', 'sense_mix_dma_kernel<BF16, 1, false, false, false>', 2),
+    # the same with the content rows gathered from the per-token table (inference, bp_sense_mix_gather)
+    ('sense_mix_dma.o', 'sense_mix_dma_kernel<BF16, 3, true, false, true>', 2),
     # training step (config 3): attention backward at d_h = 64 with and without dropout, sense-mix dC
     # dK/dV at three waves per SIMD (168 registers): ONE 64-bit value still goes to scratch, stored in front of the
     # clean-tile loop and reloaded behind it, once per pass -- no tile loop of the kernel touches scratch (round 3: 12

@@ -622,3 +622,42 @@ def test_add_layer_norm_backward_is_deterministic():
     for _ in range(3):
         for a, c in zip(first, grads()):
             assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize('shape', [(2, 1024, 16, 48, 768, 5000), (3, 300, 4, 24, 104, 97), (1, 2048, 16, 48, 256, 50264),
+                                   (2, 640, 64, 10, 640, 1000), (2, 77, 4, 16, 512, 7)])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_sense_mix_gather_equals_sense_mix_on_the_gathered_rows(shape, dtype):
+    """bp_sense_mix_gather (content rows read from a per-token table through a row index, ABI 6) against bp_sense_mix on the
+    materialised content[b, s] = table[index[b, s]]: the same kernel arithmetic on the same values -> bit-identical,
+    including partial last tiles (S = 300, 77), partial column chunks (d_out = 104), the Mini widths (d_k = 10 carried
+    as 16, k = 64) and a full-vocabulary table (1.2 GB of rows at Small's width would not fit the test: 256 columns)."""
+    bp = _bp()
+    b, s, k, dk, d, rows = shape
+    torch.manual_seed(11)
+    qk = (torch.randn(b, s, 2, k, dk, device=DEV) * 0.9).to(dtype)
+    table = torch.randn(rows, k, d, device=DEV).to(dtype)
+    index = torch.randint(0, rows, (b, s), device=DEV, dtype=torch.int32)
+    index[0, 0], index[-1, -1] = 0, rows - 1
+    assert bp.sense_mix_gather_supported(qk, table, s)
+    want = bp.sense_mix(qk, table[index.long()])
+    got = bp.sense_mix_gather(qk, table, index)
+    assert torch.equal(got, want)
+    lse = bp.sense_lse(qk)
+    out = torch.full_like(want, float('nan'))
+    assert bp.sense_mix_gather(qk, table, index, out=out, lse=lse) is out and torch.equal(out, want)
+
+
+def test_sense_mix_gather_refuses_what_it_does_not_take():
+    bp = _bp()
+    qk = torch.randn(1, 64, 2, 4, 16, device=DEV).bfloat16()
+    table = torch.randn(10, 4, 64, device=DEV).bfloat16()
+    index = torch.zeros(1, 64, device=DEV, dtype=torch.int32)
+    with pytest.raises(RuntimeError, match='int32'):
+        bp.sense_mix_gather(qk, table, index.long())
+    with pytest.raises(RuntimeError, match='table must be'):
+        bp.sense_mix_gather(qk, table[:, :3], index)
+    long_qk = torch.randn(1, 4160, 2, 4, 16, device=DEV).bfloat16()
+    assert not bp.sense_mix_gather_supported(long_qk, table, 4160)
+    with pytest.raises(RuntimeError, match='bp_sense_mix_gather'):
+        bp.sense_mix_gather(long_qk, table, torch.zeros(1, 4160, device=DEV, dtype=torch.int32))   # BP_ERR_SHAPE: the caller gathers

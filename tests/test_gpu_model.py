@@ -60,8 +60,8 @@ def test_content_dedup_matches_the_per_position_content_network():
     t = model.transformer
     ids = torch.randint(0, 96, (8, 32), device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
     calls = []
-    orig = t._content_of_unique_tokens
-    t._content_of_unique_tokens = lambda x: (calls.append(x.shape), orig(x))[1]
+    orig = t._table_of_unique_tokens
+    t._table_of_unique_tokens = lambda x: (calls.append(x.shape), orig(x))[1]
     with torch.no_grad():
         assert t._dedup_applies(ids) and not t._dedup_applies(ids[:2])        # 256 >= 192 positions; 64 < 192
         hid = t(ids)
