@@ -169,6 +169,8 @@ def pick_batch(model, make_ids, candidates, seq, device, logits, steps=3, hbm_li
     per_sample_other, fixed = None, torch.cuda.memory_allocated(device)
     largest = candidates[0]
     for b in candidates:
+        if per_sample_other is None:
+            largest = b
         if per_sample_other is not None and b > largest:
             est = fixed + (per_sample_other + logits.bytes_per_sample()) * b
             table.append(dict(batch=b, ms_per_step=None, tokens_per_s=0.0, peak_mem_gb=None,
@@ -188,7 +190,10 @@ def pick_batch(model, make_ids, candidates, seq, device, logits, steps=3, hbm_li
                 torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / steps
             peak = torch.cuda.max_memory_allocated(device)
-            if per_sample_other is None:
+            # (the footprint is taken from the first candidate large enough for the deduplicated content network --
+            # smaller ones also hold the per-position content tensor, 25 MB per sample at Small)
+            vocab = model.lm_head.weight.shape[0]
+            if per_sample_other is None and (b * seq >= 2 * vocab or b == candidates[-1]):
                 per_sample_other = max(peak - fixed - logits.bytes_per_sample() * b, 0) / b
                 fit = [c for c in candidates
                        if fixed + (per_sample_other + logits.bytes_per_sample()) * c <= hbm_limit * total_mem]
