@@ -90,6 +90,18 @@ def main():
         ms = timeit(lambda: bp_hip.sense_mix(qk, c, out=out, lse=lse), a.iters)
         res.append(dict(kernel='sense_mix', layout=a.content_layout, ms=ms, tflops=2 * pairs * d * (1 + K) * B / ms / 1e9,
                         gbps=(4 + 2 * K + 2) * S * d * B / ms / 1e6))
+    if 'mixgather' in which:
+        # the inference form: content rows read from the per-token table (50 257 distinct ids of a large batch)
+        rows = 50257
+        table = torch.randn(rows, K, d, device=dev).to(dt)
+        index = torch.randint(0, rows, (B, S), device=dev, dtype=torch.int32)
+        lse = bp_hip.sense_lse(qk)
+        out = torch.empty(B, S, d, device=dev, dtype=dt)
+        ms = timeit(lambda: bp_hip.sense_mix_gather(qk, table, index, out=out, lse=lse), a.iters)
+        # algorithmic bytes: q, k once, the table once, the index, the output
+        by = (4 * S * d + 2 * S * d + 4 * S) * B + 2 * rows * K * d
+        res.append(dict(kernel='sense_mix_gather', ms=ms, tflops=2 * pairs * d * (1 + K) * B / ms / 1e9, gbps=by / ms / 1e6,
+                        algorithmic_bytes=by))
     if 'alpha' in which:
         Ba = min(B, 64)     # (Ba, k, S, S) 16-bit: 2.1 GB at 64 x 16 x 1024^2 -- far past the 256 MiB Infinity Cache
         lse = bp_hip.sense_lse(qk[:Ba])
