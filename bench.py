@@ -421,16 +421,12 @@ def main():
             try:
                 with torch.no_grad():
                     model(ids[:b_pp], logits_out=logits_out[:b_pp])
-                torch.cuda.synchronize()
-                if dist is not None:
-                    dist.barrier()
-                t1 = time.perf_counter()
+                torch.cuda.synchronize()   # (no collective inside the try: a rank that runs out of HBM must not leave
+                t1 = time.perf_counter()   #  the others waiting in a barrier it never reaches)
                 with torch.no_grad():
                     for _ in range(n_pp):
                         model(ids[:b_pp], logits_out=logits_out[:b_pp])
                 torch.cuda.synchronize()
-                if dist is not None:
-                    dist.barrier()
                 el_pp = time.perf_counter() - t1
             except torch.OutOfMemoryError:
                 failed = 1
