@@ -409,9 +409,10 @@ def main():
     # the headline so that both numbers come from one process on one box: a few steps, same batch, same barriers.
     hbm_peak = torch.cuda.max_memory_allocated(device)
     with torch.no_grad():
-        dedup_on = bool(model.transformer._dedup_applies(ids))
+        # (a captured graph holds the per-position path: torch.unique has a data-dependent shape)
+        dedup_on = bool(model.transformer._dedup_applies(ids)) and not args.graph
     per_position = None
-    if dedup_on and not args.graph:
+    if dedup_on:
         model.transformer.dedup_content = False
         n_pp = max(1, min(args.steps, 3))
         out = None
