@@ -121,6 +121,8 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
                 // all groups' heaviest tiles first (a group's tiles together, so that its C slab is re-read while it might
                 // still be cached, gained nothing: 1.32 / 1.34 ms against 1.29 / 1.28 ms at B = 64, same fetch traffic, r02_e)
                 // (sample-major order -- one sample's twelve jobs together -- fetches 4 % less and runs 2-3 % slower, r02_w)
+                // (table form, r04_ab: walking the queue column chunk by column chunk, so that the rows in flight chip-wide are
+                // one chunk's third of the table, is 1-2 % slower at B = 64 ... 2048 -- the memory-side cache does not pay it back)
                 const int slot = idx / groups;
                 const int grp = mix_queue_group(p.n_chunks, q, idx - slot * groups);
                 return grp * 256 + (p.n_qtiles - 1 - slot);

@@ -74,7 +74,7 @@ def main():
         # 5 matmuls of the textbook backward (S, dP, dV, dK, dQ); this split recomputes S and dP once more
         fl, by = 10 * (pairs if causal else S * S) * D * H * B, 16 * S * D * H * B
         res.append(dict(kernel='flash_bwd(dkdv+dq+dsum)', ms=ms, tflops=fl / ms / 1e9, gbps=by / ms / 1e6))
-    if {'lse', 'mix', 'alpha', 'mixbwd'} & set(which):
+    if {'lse', 'mix', 'mixgather', 'alpha', 'mixbwd'} & set(which):
         qk = torch.randn(B, S, 2, K, d // K, device=dev).to(dt)
     if 'lse' in which:
         ms = timeit(lambda: bp_hip.sense_lse(qk), a.iters)
