@@ -72,6 +72,34 @@ def test_small_config2_whole_model_seq1024():
         assert err <= 3 * b + 1e-3, (name, err, b)
 
 
+def test_small_config2_content_once_per_distinct_token_equals_per_position():
+    """Backpack-Small at the smallest batch where inference takes the deduplicated content path (100 x 1024 positions
+    >= 2 x 50 264 vocabulary entries): hidden states against the same model with the content network run on every
+    position (which `test_small_config2_whole_model_seq1024` pins to the oracle).  The mix kernel's arithmetic is
+    bit-identical on identical rows; what may differ is the BLAS GEMMs' output for a row when the row count changes
+    (50 k distinct tokens against 102 k positions), i.e. bf16 rounding noise."""
+    ocfg = R.make_config('small', n_positions=1024, vocab_size=50264)
+    sd = R.init_state_dict(ocfg, seed=0)
+    with torch.no_grad():
+        sd['transformer.contextualization_attn.Wqkv.weight'].mul_(8.0)
+        sd = {k: v.bfloat16().float() for k, v in sd.items()}
+    sd['lm_head.weight'] = sd['transformer.gpt2_model.embeddings.word_embeddings.weight']
+    model = _model_from_sd_keys(sd, ocfg, torch.bfloat16, True, True)
+    t = model.transformer
+    ids = torch.randint(0, 50257, (100, 1024), generator=torch.Generator().manual_seed(5)).to(DEV)
+    with torch.no_grad():
+        assert t._dedup_applies(ids) and not t._dedup_applies(ids[:98])
+        got = t(ids)
+        t.dedup_content = False
+        want = t(ids)
+        t.dedup_content = True
+    diff = (got.float() - want.float()).abs().max().item()
+    scale = want.float().abs().max().item()
+    print(f'dedup vs per-position hidden: max|diff| {diff:.3e} of {scale:.2f}; identical elements '
+          f'{(got == want).float().mean().item():.4f}')
+    assert torch.isfinite(got.float()).all() and diff <= 2 ** -7 * scale
+
+
 def test_small_config5_whole_model_seq4096_fp16():
     """BASELINE config 5 as a whole model (round-3 review: only the two kernels were checked at S = 4096): Backpack-Small,
     B = 1, S = 4096, fp16, HIP path against the fp32 CPU oracle of the reference's eager forward

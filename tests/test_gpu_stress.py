@@ -208,3 +208,45 @@ def test_null_queue_ws_is_refused_under_graph_capture():
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, want) and torch.equal(dc, want_dc)
+
+
+def test_gathering_mix_repeats_bit_identically_and_replays_from_a_graph():
+    """bp_sense_mix_gather keeps a per-job table of row offsets in LDS behind the DMA ring: repeated launches with other
+    work in flight, launches on two streams at once and a captured graph all give the bits of bp_sense_mix on the gathered
+    rows."""
+    bp = _bp()
+    torch.manual_seed(12)
+    b, s, k, dk, d, rows = 3, 1024, 16, 48, 768, 4099
+    qk = (torch.randn(b, s, 2, k, dk, device=DEV) * 0.9).bfloat16()
+    table = torch.randn(rows, k, d, device=DEV).bfloat16()
+    index = torch.randint(0, rows, (b, s), device=DEV, dtype=torch.int32)
+    lse = bp.sense_lse(qk)
+    want = bp.sense_mix(qk, table[index.long()], lse=lse).clone()
+    side = torch.cuda.Stream()
+    for i in range(10):
+        keep = _noise(side, 2 + i % 3)
+        assert torch.equal(bp.sense_mix_gather(qk, table, index, lse=lse), want), f'repetition {i} differs'
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    torch.cuda.synchronize()
+    outs = []
+    for st in streams:
+        with torch.cuda.stream(st):
+            for _ in range(3):
+                out = bp.sense_mix_gather(qk, table, index, lse=lse)
+            outs.append(out)
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, want) for o in outs)
+    warm = torch.cuda.Stream()
+    warm.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(warm):
+        bp.sense_mix_gather(qk, table, index, lse=lse)
+    torch.cuda.current_stream().wait_stream(warm)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out_g = bp.sense_mix_gather(qk, table, index, lse=lse)
+    for _ in range(5):
+        out_g.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out_g, want)
+    del keep
