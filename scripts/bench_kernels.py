@@ -92,7 +92,7 @@ def main():
                         gbps=(4 + 2 * K + 2) * S * d * B / ms / 1e6))
     if 'mixgather' in which:
         # the inference form: content rows read from the per-token table (50 257 distinct ids of a large batch)
-        rows = 50257
+        rows = int(os.environ.get('BP_BENCH_TABLE_ROWS', '50257'))   # (a few rows = an L2-resident table: what the kernel does without HBM)
         table = torch.randn(rows, K, d, device=dev).to(dt)
         index = torch.randint(0, rows, (B, S), device=dev, dtype=torch.int32)
         lse = bp_hip.sense_lse(qk)
