@@ -73,6 +73,18 @@ def test_content_dedup_matches_the_per_position_content_network():
         logits_pp = model(ids).logits
         assert len(calls) == 2
         t.dedup_content = True
+    # shapes the gathering kernel does not take (S > 4096, a table of 4 GiB or more): the rows are gathered by torch and
+    # the dense kernel runs -- the same bits
+    import bp_hip
+    supported = bp_hip.sense_mix_gather_supported
+    bp_hip.sense_mix_gather_supported = lambda *a, **kw: False
+    try:
+        with torch.no_grad():
+            assert torch.equal(t(ids), hid)
+    finally:
+        bp_hip.sense_mix_gather_supported = supported
+    assert len(calls) == 3
+    calls.pop()
     assert not t._dedup_applies(ids)                                          # autograd enabled
     model.train()
     with torch.no_grad():
