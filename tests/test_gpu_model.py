@@ -325,6 +325,28 @@ def test_bench_script_contract():
     assert {k['kernel'] for k in d['kernels']} >= {'flash_fwd_kernel', 'sense_mix_kernel', 'add_layer_norm_kernel'}
 
 
+def test_bench_reports_both_content_orders():
+    """At a batch where inference takes the deduplicated content path (1024 x 128 positions >= 2 x vocab), the bench line
+    says so and carries the per-position order timed in the same process; --no-content-dedup makes that the headline."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    base = [sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', 'micro-128', '--batch', '1024', '--steps', '3',
+            '--warmup', '1', '--no-cpu-baseline']
+    out = subprocess.run(base, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])
+    assert d['config']['content_network'].startswith('once per distinct token')
+    pp = d['content_per_position']
+    assert pp['value'] > 0 and pp['steps'] == 3 and pp['batch_per_gpu'] == 1024 and pp['unit'] == 'tokens/s'
+    out = subprocess.run(base + ['--no-content-dedup'], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d2 = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])
+    assert d2['config']['content_network'] == 'once per position' and 'content_per_position' not in d2
+
+
 def test_greedy_generation_on_the_hip_path():
     """model.generate on the HIP path (the sequence grows by one token per step, so every call meets a new,
     unaligned sequence length).  EVERY step is checked: the token appended at position t must be the HIP
