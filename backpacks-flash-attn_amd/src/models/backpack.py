@@ -279,8 +279,7 @@ class BackpackModel(GPTPreTrainedModel):
                 return bp_hip.sense_mix_gather(qk, rows, inverse.to(torch.int32), self.contextualization_attn.scale())
             content = torch.nn.functional.embedding(inverse, rows.reshape(rows.shape[0], -1))
             return bp_hip.sense_mix(qk, content.view(*input_ids.shape, *rows.shape[1:]), self.contextualization_attn.scale())
-        else:
-            content = self.content_model(input_ids, position_ids, inference_params)   # (B,k,S,d) view
+        content = self.content_model(input_ids, position_ids, inference_params)   # (B,k,S,d) view
         if self.use_hip:
             # fused: softmax_causal(q_l k_l^T) @ C_l summed over senses, alpha never stored
             qk = self.contextualization_attn.project(contextl_hidden_states)
