@@ -625,7 +625,8 @@ def test_add_layer_norm_backward_is_deterministic():
 
 
 @pytest.mark.parametrize('shape', [(2, 1024, 16, 48, 768, 5000), (3, 300, 4, 24, 104, 97), (1, 2048, 16, 48, 256, 50264),
-                                   (2, 640, 64, 10, 640, 1000), (2, 77, 4, 16, 512, 7)])
+                                   (2, 640, 64, 10, 640, 1000), (2, 77, 4, 16, 512, 7), (1, 2048, 4, 80, 256, 300),
+                                   (1, 4096, 4, 48, 256, 300)])
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 def test_sense_mix_gather_equals_sense_mix_on_the_gathered_rows(shape, dtype):
     """bp_sense_mix_gather (content rows read from a per-token table through a row index, ABI 6) against bp_sense_mix on the
@@ -659,5 +660,7 @@ def test_sense_mix_gather_refuses_what_it_does_not_take():
         bp.sense_mix_gather(qk, table[:, :3], index)
     long_qk = torch.randn(1, 4160, 2, 4, 16, device=DEV).bfloat16()
     assert not bp.sense_mix_gather_supported(long_qk, table, 4160)
+    wide_qk = torch.randn(1, 2112, 2, 4, 80, device=DEV).bfloat16()      # d_k > 64: the ring leaves room for 2048 keys
+    assert not bp.sense_mix_gather_supported(wide_qk, table, 2112)
     with pytest.raises(RuntimeError, match='bp_sense_mix_gather'):
         bp.sense_mix_gather(long_qk, table, torch.zeros(1, 4160, device=DEV, dtype=torch.int32))   # BP_ERR_SHAPE: the caller gathers
