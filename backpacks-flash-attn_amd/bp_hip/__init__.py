@@ -29,7 +29,10 @@ _eager_fallback = False
 @contextlib.contextmanager
 def allow_eager_fallback(enabled=True):
     """Within the block, backward passes whose shape the fused HIP kernels do not take may use the slower routes named
-    above (they need (B, k, S, S)-sized buffers / eager attention).  The flag is read when BACKWARD runs."""
+    above (they need (B, k, S, S)-sized buffers / eager attention).  Wrapping EITHER the forward or the backward() call is
+    enough: the autograd Functions record the flag in their context at forward time (`fallback_recorded`) and also read it
+    when backward runs.  The flag itself is process-wide on purpose: autograd runs the backward of CUDA tensors on its own
+    device thread, where a thread-local set by the caller of backward() would not be seen."""
     global _eager_fallback
     previous, _eager_fallback = _eager_fallback, bool(enabled)
     try:
@@ -38,8 +41,9 @@ def allow_eager_fallback(enabled=True):
         _eager_fallback = previous
 
 
-def eager_fallback_allowed():
-    return _eager_fallback
+def eager_fallback_allowed(ctx=None):
+    """The flag now, or what `ctx` (an autograd context) recorded when its forward ran."""
+    return bool(_eager_fallback or getattr(ctx, 'fallback_recorded', False))
 
 
 _i32, _i64, _f32, _ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
@@ -190,10 +194,9 @@ def flash_fwd(q, k, v, out, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen
             raise RuntimeError('bp_hip.flash_fwd: fixed-length batch does not divide total rows')
     if batch <= 0:
         raise RuntimeError('bp_hip.flash_fwd: empty batch')
-    if cu_seqlens_q is not None and total_q == batch * max_seqlen_q and k.shape[0] == batch * max_seqlen_k:
-        # no sequence is longer than max_seqlen, so all of them have exactly that length: the fixed-length entry of the
-        # C ABI computes the same offsets without reading cu_seqlens in every workgroup (-3 % at B = 64, r04_s)
-        cu_seqlens_q = cu_seqlens_k = None
+    # (Callers that KNOW the batch is fixed-length pass cu_seqlens = None -- the modules of this package do; the row
+    # count alone does not say so: an over-allocated (B * max_seqlen)-row buffer with shorter sequences in cu_seqlens is
+    # legal, as in the reference's mha_fwd, which only reads the offsets.)
     lse_len = round_up(max_seqlen_q, 16)
     lse = torch.empty((batch, nheads, lse_len), dtype=torch.float32, device=q.device)
     with torch.cuda.device(q.device):
@@ -262,8 +265,6 @@ def flash_bwd(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seql
             raise RuntimeError('bp_hip.flash_bwd: fixed-length batch does not divide total rows')
     if batch <= 0:
         raise RuntimeError('bp_hip.flash_bwd: empty batch')
-    if cu_seqlens_q is not None and total_q == batch * max_seqlen_q and k.shape[0] == batch * max_seqlen_k:
-        cu_seqlens_q = cu_seqlens_k = None   # (all sequences have the maximum length: see flash_fwd)
     if softmax_lse.dtype != torch.float32 or not softmax_lse.is_contiguous() or \
             softmax_lse.shape != (batch, nheads, round_up(max_seqlen_q, 16)):
         raise RuntimeError('bp_hip.flash_bwd: softmax_lse must be the contiguous fp32 (batch, nheads, '
@@ -647,6 +648,7 @@ class SenseMixFn(torch.autograd.Function):
         out = sense_mix(qk, content, scale, lse=lse, key_weight=key_weight)
         ctx.save_for_backward(qk, content, lse, key_weight)
         ctx.scale = scale
+        ctx.fallback_recorded = eager_fallback_allowed()
         return out
 
     @staticmethod
@@ -654,11 +656,11 @@ class SenseMixFn(torch.autograd.Function):
         qk, content, lse, key_weight = ctx.saved_tensors
         dout = dout.contiguous()
         if not _fused_mix_backward_ok(qk, content, key_weight):
-            if not eager_fallback_allowed():
+            if not eager_fallback_allowed(ctx):
                 raise RuntimeError(
                     'bp_hip.SenseMixFn.backward: the fused backward kernels take d_k % 8 == 0, d_out % 8 == 0, a contiguous '
                     '(B,S,k,d) content and no key_weight; this call would take the alpha-rebuilding route (two (B,k,S,S) '
-                    'buffers + BLAS GEMMs).  Opt in with `with bp_hip.allow_eager_fallback():` around backward().')
+                    'buffers + BLAS GEMMs).  Opt in with `with bp_hip.allow_eager_fallback():` around the forward or around backward().')
             return _sense_mix_backward_rebuild(ctx, qk, content, lse, key_weight, dout)
         dcontent = sense_mix_dc(qk, dout, lse, ctx.scale, content) if ctx.needs_input_grad[1] else None
         dqk = sense_dqk(qk, content, dout, lse, ctx.scale) if ctx.needs_input_grad[0] else None
@@ -911,6 +913,9 @@ class GraphedForward:
     def __init__(self, module, example_input, select=lambda out: getattr(out, 'logits', out)):
         self.static_in = example_input.clone()
         self.select = select
+        # caches a module keeps OUTSIDE the graph (the Backpack model's whole-vocabulary sense table): refreshed in place
+        # in front of every replay, so in-place weight updates reach the replays as they reach the captured kernels
+        self.refresh = getattr(module, 'refresh_inference_caches', None)
         side = torch.cuda.Stream(device=example_input.device)
         side.wait_stream(torch.cuda.current_stream(example_input.device))
         with torch.cuda.stream(side), torch.no_grad():
@@ -923,5 +928,8 @@ class GraphedForward:
 
     def __call__(self, x):
         self.static_in.copy_(x)
+        if self.refresh is not None:
+            with torch.no_grad():
+                self.refresh()
         self.graph.replay()
         return self.static_out

@@ -355,7 +355,7 @@ int bp_sense_mix_gather(const void *qk, const void *table, const int32_t *row_in
     }
     bp::MixParams p{};
     p.q = qp; p.k = qp + qk_two_stride; p.c = table; p.o = out; p.lse = lse_ws;
-    p.row_index = row_index; p.idx_bs = idx_batch_stride;
+    p.row_index = row_index; p.idx_bs = idx_batch_stride; p.last_table_row = (uint32_t)(table_rows - 1);
     p.qk_bs = qk_batch_stride; p.qk_rs = qk_row_stride; p.qk_ss = qk_sense_stride;
     p.c_bs = 0; p.c_rs = t_row_stride; p.c_ss = t_sense_stride;
     p.o_bs = o_batch_stride; p.o_rs = o_row_stride;

@@ -78,6 +78,7 @@ struct MixParams {
     int64_t kw_bs, kw_ss;
     const int32_t *row_index; // optional (bp_sense_mix_gather): content[b, s, l, :] = c + row_index[b*idx_bs + s]*c_rs + l*c_ss
     int64_t idx_bs;
+    uint32_t last_table_row;  // table_rows - 1: indices are clamped to it (unsigned, so a negative index also lands there)
     int64_t qk_bs, qk_rs, qk_ss;
     int64_t c_bs, c_rs, c_ss;
     int64_t o_bs, o_rs;

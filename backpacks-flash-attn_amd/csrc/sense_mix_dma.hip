@@ -199,7 +199,8 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
             const int32_t *idx = p.row_index + (int64_t)batch * p.idx_bs;
             const uint32_t row_bytes = (uint32_t)p.c_rs * 2u;
             for (int i = tid; i < nkb * C::BK; i += C::NT)
-                *reinterpret_cast<uint32_t *>(smem + C::GATHER_OFF + i * 4) = (uint32_t)idx[min(i, S - 1)] * row_bytes;
+                *reinterpret_cast<uint32_t *>(smem + C::GATHER_OFF + i * 4) =
+                    min((uint32_t)idx[min(i, S - 1)], p.last_table_row) * row_bytes;   // an index outside the table reads its last row, never outside it
             __syncthreads();
         }
 

@@ -90,6 +90,7 @@ class _FlashAttnFuncBase(torch.autograd.Function):
         ctx.dropout_p, ctx.rng_state = dropout_p, rng_state
         ctx.softmax_scale, ctx.causal = softmax_scale, causal
         ctx.max_q, ctx.max_k = max_q, max_k
+        ctx.fallback_recorded = bp_hip.eager_fallback_allowed()
         return out, lse, S
 
     @staticmethod
@@ -104,10 +105,10 @@ class _FlashAttnFuncBase(torch.autograd.Function):
                                         rng_state=ctx.rng_state)
         if ctx.dropout_p > 0.0:
             raise RuntimeError('flash_attn (gfx950 build): attention dropout needs head_dim % 8 == 0 and <= 128')
-        if not bp_hip.eager_fallback_allowed():
+        if not bp_hip.eager_fallback_allowed(ctx):
             raise RuntimeError(
                 'flash_attn (gfx950 build): the HIP backward takes head_dim %% 8 == 0 and <= 128 (got %d); differentiating '
-                'an eager recomputation instead is opt-in: `with bp_hip.allow_eager_fallback():` around backward()'
+                'an eager recomputation instead is opt-in: `with bp_hip.allow_eager_fallback():` around the forward or backward()'
                 % q.shape[-1])
         with torch.enable_grad():
             q_, k_, v_ = (t.detach().requires_grad_() for t in (q, k, v))

@@ -41,6 +41,7 @@ class DropoutAddLayerNormFn(torch.autograd.Function):
         ctx.eps, ctx.prenorm, ctx.residual_dtype = epsilon, prenorm, residual_dtype
         ctx.x0_dtype, ctx.has_x1 = x0.dtype, x1 is not None
         ctx.dropout_p, ctx.rng_state = dropout_p, rng_state
+        ctx.fallback_recorded = bp_hip.eager_fallback_allowed()
         result = (z, x) if prenorm else (z,)
         if return_dmask:
             ctx.mark_non_differentiable(dmask)
@@ -61,10 +62,10 @@ class DropoutAddLayerNormFn(torch.autograd.Function):
                     (rest[0] if colscale is not None else None), None, None, None, None, None)
         if ctx.dropout_p > 0.0 or rowscale is not None or colscale is not None:
             raise RuntimeError('dropout_add_layer_norm (gfx950 build): fused dropout / rowscale / layerscale need <= 2048 columns')
-        if not bp_hip.eager_fallback_allowed():
+        if not bp_hip.eager_fallback_allowed(ctx):
             raise RuntimeError('dropout_add_layer_norm (gfx950 build): the HIP backward takes rows of up to 2048 columns (got '
                                '%d); differentiating the eager expression instead is opt-in: '
-                               '`with bp_hip.allow_eager_fallback():` around backward()' % xsum.shape[-1])
+                               '`with bp_hip.allow_eager_fallback():` around the forward or backward()' % xsum.shape[-1])
         with torch.enable_grad():   # wide rows: differentiate the eager expression
             a = xsum.detach().float().requires_grad_()
             g, bt = gamma.detach().requires_grad_(), beta.detach().requires_grad_()

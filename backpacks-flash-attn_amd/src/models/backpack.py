@@ -233,6 +233,11 @@ class BackpackModel(GPTPreTrainedModel):
         self.use_hip = bool(getattr(config, 'use_flash_attn', False))
         self.num_content_vectors = config.num_content_vectors
         self.dedup_content = bool(getattr(config, 'dedup_content', True))
+        self.sense_table_mode = getattr(config, 'sense_table', 'cached')      # 'cached' | 'batch' | 'off', see below
+        assert self.sense_table_mode in ('cached', 'batch', 'off')
+        # 'batch' mode pays from about this many positions up (measured, profiles/r05_*_content_modes.jsonl)
+        self.dedup_min_positions = int(getattr(config, 'dedup_min_positions', 2 * config.vocab_size))
+        self._sense_table = None
         self.gpt2_model = GPTModel(config, **factory_kwargs)
         self.content_model = BackpackContentModule(config, self.num_content_vectors,
                                                    self.gpt2_model.embeddings, **factory_kwargs)
@@ -245,16 +250,78 @@ class BackpackModel(GPTPreTrainedModel):
         """HF GPT-2 weights into the trunk only (see BackpackPreTrainedModel.from_pretrained)."""
         return _load_gpt2_trunk(cls(config, *inputs, **kwargs), model_name, config, state_dict)
 
+    # ---- inference: the content network once per TOKEN instead of once per position ---------------------------------
+    # The sense vectors C_l(x_j) are a function of the token alone (no positions, reference :258; an Identity mixer,
+    # :130-143; everything else per-token LayerNorm / MLP).  In inference (HIP path, eval(), no autograd graph) the
+    # content network therefore needs one row per token id, and the mix kernel reads the rows through an index
+    # (bp_sense_mix_gather).  Two tables, chosen by `config.sense_table` / `self.sense_table_mode`:
+    #   'cached' (default)  the WHOLE vocabulary, built once per weight version (`sense_table()`); index = the ids.
+    #                       Static shapes, no host sync: every batch size, graph capture, generate(cg=True).
+    #   'batch'             the distinct ids of THIS batch (torch.unique, a host sync), rebuilt every forward; taken from
+    #                       `dedup_min_positions` positions up (below that the per-position order is as fast).
+    #   'off'               every position through the content network (the reference's order; also `dedup_content=False`).
+    # Mathematically identical to the per-position order; bits can differ where the BLAS GEMMs round a row differently
+    # when the row count changes.  Training always runs per position (dropout inside the content network, autograd).
+
+    def _token_table_allowed(self, input_ids):
+        return (self.dedup_content and self.sense_table_mode != 'off' and self.use_hip and not self.training
+                and not torch.is_grad_enabled() and input_ids.is_cuda)
+
     def _dedup_applies(self, input_ids):
-        """The sense vectors C_l(x_j) are a function of the token alone (no positions, reference :258; an Identity mixer,
-        :130-143), so in inference the content network needs one row per DISTINCT token of the batch, not one per position:
-        at the HBM-filling batch (1.7 M positions, at most 50 264 distinct ids) that is 34 times less work for 27 % of the
-        model's GEMM flops.  Taken only where it is exact and pays by construction: the HIP path, no dropout (eval), no
-        autograd graph, not while a stream is being captured (torch.unique has a data-dependent shape), and at least twice
-        as many positions as vocabulary entries."""
-        return (self.dedup_content and self.use_hip and not self.training and not torch.is_grad_enabled()
-                and input_ids.is_cuda and input_ids.numel() >= 2 * self.embeddings.word_embeddings.weight.shape[0]
-                and not torch.cuda.is_current_stream_capturing())
+        """True when this forward builds the table of the batch's distinct tokens ('batch' mode, or 'cached' mode whose
+        table cannot be kept -- inference-mode parameters).  Never while a stream is being captured: torch.unique has a
+        data-dependent shape."""
+        if not self._token_table_allowed(input_ids) or torch.cuda.is_current_stream_capturing():
+            return False
+        if self.sense_table_mode == 'cached' and self.sense_table() is not None:
+            return False
+        return input_ids.numel() >= self.dedup_min_positions
+
+    def _sense_table_key(self):
+        params = list(self.content_model.parameters())
+        if any(p.is_inference() for p in params):
+            return None                       # no version counter to key a cache on
+        return tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in params)
+
+    def sense_table(self):
+        """(vocab rows, k, d): the content network's output for EVERY row of the word embedding, kept until a parameter of
+        the content model changes (`_version` moves on every in-place update, `data_ptr` on a reload / `.to()`), dropped
+        by `.train()`.  A refresh writes into the SAME storage, so a captured HIP graph that reads the table sees the new
+        rows (GraphedForward / generate(cg=True) call `refresh_inference_caches()` in front of a replay).  Returns None
+        when nothing can be kept (inference-mode parameters) or when the table would have to be built while a stream is
+        capturing.  1.2 GB at Backpack-Small, 4.1 GB at Mini k = 64; ~5 ms to build."""
+        key = self._sense_table_key()
+        if key is None:
+            return None
+        cached = self._sense_table
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        weight = self.embeddings.word_embeddings.weight
+        if weight.is_cuda and torch.cuda.is_current_stream_capturing():
+            return None
+        with torch.inference_mode(False), torch.no_grad():
+            was_training = self.content_model.training
+            self.content_model.eval()
+            ids = torch.arange(weight.shape[0], device=weight.device).unsqueeze(0)
+            rows = self.content_model(ids)[0].transpose(0, 1)      # (V,k,d): the (1,V,k*d) block as it lies
+            self.content_model.train(was_training)
+            if cached is not None and cached[1].shape == rows.shape and cached[1].dtype == rows.dtype \
+                    and cached[1].device == rows.device:
+                cached[1].copy_(rows)
+                rows = cached[1]
+        self._sense_table = (key, rows)
+        return rows
+
+    def refresh_inference_caches(self):
+        """Bring the cached sense table up to date with the weights (a no-op when it is); call in front of replaying a
+        captured graph of this model after an in-place weight update."""
+        if self.sense_table_mode == 'cached' and self.dedup_content and self.use_hip and not self.training:
+            self.sense_table()
+
+    def train(self, mode=True):
+        if mode:
+            self._sense_table = None          # training runs per position; do not hold 1-4 GB of stale rows
+        return super().train(mode)
 
     def _table_of_unique_tokens(self, input_ids):
         """(rows (U, k, d) = the content network's output for the sorted distinct ids, index (B, S) of every position's row)"""
@@ -268,17 +335,26 @@ class BackpackModel(GPTPreTrainedModel):
         content = torch.nn.functional.embedding(inverse, rows.reshape(u, k * d))   # (B,S,k*d): every position's row
         return content.view(*input_ids.shape, k, d).transpose(1, 2)    # (B,k,S,d) view, as content_model returns it
 
+    def _mix_from_table(self, hidden, rows, index):
+        qk = self.contextualization_attn.project(hidden)
+        if bp_hip.sense_mix_gather_supported(qk, rows, index.shape[1]):
+            # the mix kernel reads the table rows itself: no (B,S,k,d) content tensor at all
+            return bp_hip.sense_mix_gather(qk, rows, index.to(torch.int32), self.contextualization_attn.scale())
+        # shapes the gathering kernel does not take (S > 4096, a table of 4 GiB or more): torch gathers the rows
+        content = torch.nn.functional.embedding(index, rows.reshape(rows.shape[0], -1))
+        return bp_hip.sense_mix(qk, content.view(*index.shape, *rows.shape[1:]), self.contextualization_attn.scale())
+
     def forward(self, input_ids, position_ids=None, inference_params=None):
         contextl_hidden_states = self.gpt2_model(input_ids, position_ids=position_ids,
                                                  inference_params=inference_params)
-        if self._dedup_applies(input_ids):
-            rows, inverse = self._table_of_unique_tokens(input_ids)
-            qk = self.contextualization_attn.project(contextl_hidden_states)
-            if bp_hip.sense_mix_gather_supported(qk, rows, input_ids.shape[1]):
-                # the mix kernel reads the table rows itself: no (B,S,k,d) content tensor at all
-                return bp_hip.sense_mix_gather(qk, rows, inverse.to(torch.int32), self.contextualization_attn.scale())
-            content = torch.nn.functional.embedding(inverse, rows.reshape(rows.shape[0], -1))
-            return bp_hip.sense_mix(qk, content.view(*input_ids.shape, *rows.shape[1:]), self.contextualization_attn.scale())
+        if self._token_table_allowed(input_ids):
+            if self.sense_table_mode == 'cached':
+                rows = self.sense_table()
+                if rows is not None:
+                    return self._mix_from_table(contextl_hidden_states, rows, input_ids)
+            if self._dedup_applies(input_ids):
+                rows, inverse = self._table_of_unique_tokens(input_ids)
+                return self._mix_from_table(contextl_hidden_states, rows, inverse)
         content = self.content_model(input_ids, position_ids, inference_params)   # (B,k,S,d) view
         if self.use_hip:
             # fused: softmax_causal(q_l k_l^T) @ C_l summed over senses, alpha never stored
@@ -335,6 +411,15 @@ class BackpackLMHeadModel(BackpackPreTrainedModel, GenerationMixin):
         if tuple(logits_out.shape) != tuple(want) or logits_out.dtype != hidden_states.dtype \
                 or not logits_out.is_contiguous():
             raise RuntimeError(f'logits_out must be a contiguous {tuple(want)} tensor of {hidden_states.dtype}')
+        # `out=` bypasses autocast and module hooks: the operands must already agree (fp32 weights under bf16 autocast
+        # would need a cast of the 39 M-entry matrix per call -- convert the model instead), and there is no bias to add
+        if self.lm_head.bias is not None or self.lm_head.weight.dtype != hidden_states.dtype:
+            raise RuntimeError(f'logits_out needs a bias-free lm_head whose weight has the activation dtype '
+                               f'({self.lm_head.weight.dtype} vs {hidden_states.dtype}); call model.to(dtype) first')
         torch.mm(hidden_states.reshape(-1, hidden_states.shape[-1]), self.lm_head.weight.t(),
                  out=logits_out.view(-1, want[-1]))
         return CausalLMOutput(logits=logits_out)
+
+    def refresh_inference_caches(self):
+        """See BackpackModel.refresh_inference_caches (the cached whole-vocabulary sense table)."""
+        self.transformer.refresh_inference_caches()

@@ -273,9 +273,14 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-threads', type=int, default=None)
     ap.add_argument('--no-kernel-events', action='store_true')
-    ap.add_argument('--no-content-dedup', action='store_true',
-                    help='run the content (sense) network on every position, as the reference does, instead of once per '
-                         'distinct token of the batch (src/models/backpack.py: BackpackModel._dedup_applies)')
+    ap.add_argument('--content', default=None, choices=['batch', 'cached', 'position'],
+                    help="how the timed step gets its sense vectors (src/models/backpack.py, BackpackModel.sense_table_mode): "
+                         "'batch' (default for eager launches) = content network once per distinct token id of the batch, the "
+                         "table rebuilt EVERY step; 'cached' (default with --graph: the only per-token form a graph can hold) = "
+                         "the whole-vocabulary table built once per weight version, outside the timed region; 'position' = "
+                         "the reference's order, every position through the content network.  The other two orders are timed "
+                         "for a few steps in the same process and reported next to `value`.")
+    ap.add_argument('--no-content-dedup', action='store_true', help="same as --content position")
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
                     help="'nccl' (= RCCL, one rank per GPU) for every real run; 'gloo' moves the same collectives "
                          "through host memory and lets several ranks share one GPU -- the test-suite's world-size-2 run "
@@ -310,8 +315,11 @@ def main():
     model_name, seq, dtype_name, default_batch = WORKLOADS[args.workload]
     dtype = torch.bfloat16 if dtype_name == 'bf16' else torch.float16
     cfg, model = build_model(model_name, seq, dtype, device)
-    if args.no_content_dedup:
-        model.transformer.dedup_content = False
+    MODES = {'batch': 'batch', 'cached': 'cached', 'position': 'off'}
+    content = 'position' if args.no_content_dedup else (args.content or ('cached' if args.graph else 'batch'))
+    if args.graph and content == 'batch':
+        raise SystemExit("--graph cannot hold --content batch (torch.unique has a data-dependent shape)")
+    model.transformer.sense_table_mode = MODES[content]
 
     def make_ids(b):
         return torch.randint(0, 50257, (b, seq), device=device,
@@ -405,30 +413,36 @@ def main():
     clock.enabled = False
     assert out.shape == (batch, seq, cfg.vocab_size) and bool(torch.isfinite(out[0, -1].float()).all())
 
-    # The same step with the content network run on every POSITION (the reference's order of operations), timed next to
-    # the headline so that both numbers come from one process on one box: a few steps, same batch, same barriers.
+    # The same step in the OTHER content orders (the reference's per-position order among them), timed next to the headline
+    # so that all numbers come from one process on one box: a few steps, same batch, same barriers.
     hbm_peak = torch.cuda.max_memory_allocated(device)
     with torch.no_grad():
-        # (a captured graph holds the per-position path: torch.unique has a data-dependent shape)
-        dedup_on = bool(model.transformer._dedup_applies(ids)) and not args.graph
-    per_position = None
-    if dedup_on:
-        model.transformer.dedup_content = False
-        n_pp = max(1, min(args.steps, 3))
-        out = None
-        b_pp = batch   # the per-position content tensor needs 25 MB per sample more: step down if the batch does not fit
-        while per_position is None:
-            failed = 0
+        # which order the timed steps actually ran ('batch' falls back to per position under 2 x vocab positions)
+        if content == 'batch' and not model.transformer._dedup_applies(ids):
+            content = 'position'
+        if content == 'cached' and model.transformer.sense_table() is None:
+            content = 'position'
+
+    def time_other(mode):
+        """tokens/s of min(steps, 3) eager steps with sense_table_mode = `mode` at the headline batch (3/4 of it, repeatedly,
+        if the 25 MB per sample of per-position content tensor no longer fit)."""
+        model.transformer.sense_table_mode = MODES[mode]
+        n = max(1, min(args.steps, 3))
+        b_o, result = batch, None
+        while result is None:
+            failed, el = 0, 0.0
             try:
                 with torch.no_grad():
-                    model(ids[:b_pp], logits_out=logits_out[:b_pp])
+                    if mode == 'batch' and not model.transformer._dedup_applies(ids[:b_o]):
+                        return dict(value=None, note='fewer than 2 x vocab positions: this order does not apply')
+                    model(ids[:b_o], logits_out=logits_out[:b_o])
                 torch.cuda.synchronize()   # (no collective inside the try: a rank that runs out of HBM must not leave
                 t1 = time.perf_counter()   #  the others waiting in a barrier it never reaches)
                 with torch.no_grad():
-                    for _ in range(n_pp):
-                        model(ids[:b_pp], logits_out=logits_out[:b_pp])
+                    for _ in range(n):
+                        model(ids[:b_o], logits_out=logits_out[:b_o])
                 torch.cuda.synchronize()
-                el_pp = time.perf_counter() - t1
+                el = time.perf_counter() - t1
             except torch.OutOfMemoryError:
                 failed = 1
             if dist is not None:
@@ -438,17 +452,24 @@ def main():
             if failed:
                 torch.cuda.synchronize()
                 torch.cuda.empty_cache()
-                b_pp = b_pp * 3 // 4
-                if b_pp < 1:
-                    per_position = dict(value=None, note='out of HBM with the content network run per position')
+                b_o = b_o * 3 // 4
+                if b_o < 1:
+                    return dict(value=None, note='out of HBM')
                 continue
             if dist is not None:
-                t = torch.tensor([el_pp], device=device, dtype=torch.float64)
+                t = torch.tensor([el], device=device, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                el_pp = float(t.item())
-            per_position = dict(value=round(world * b_pp * seq * n_pp / el_pp, 1), unit='tokens/s', steps=n_pp,
-                                ms_per_step=round(el_pp / n_pp * 1e3, 3), batch_per_gpu=b_pp)
-        model.transformer.dedup_content = True
+                el = float(t.item())
+            result = dict(value=round(world * b_o * seq * n / el, 1), unit='tokens/s', steps=n,
+                          ms_per_step=round(el / n * 1e3, 3), batch_per_gpu=b_o)
+        return result
+
+    others = {}
+    out = None
+    for mode in ('position', 'cached', 'batch'):
+        if mode != content and not args.graph:   # (a replayed graph against eager launches would compare launch overheads)
+            others[mode] = time_other(mode)
+    model.transformer.sense_table_mode = MODES[content]
 
     if dist is not None:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -493,12 +514,20 @@ def main():
                        'batch_per_gpu': batch, 'global_batch': batch * world, 'seq_len': seq,
                        'batch_choice': 'auto: largest batch within 1 % of the best rate in batch_sweep (candidates up to 90 % of HBM; logits in one persistent block)' if sweep else 'given',
                        'hbm_frac_peak': round(hbm_peak / torch.cuda.get_device_properties(device).total_memory, 3),
-                       'content_network': ('once per distinct token id of the batch (torch.unique; the mix kernel gathers the rows; exact: the '
-                                           'sense vectors depend on the token alone)' if dedup_on else 'once per position'),
+                       'content_network': {
+                           'batch': 'once per distinct token id of the batch, EVERY step (torch.unique; the mix kernel gathers the '
+                                    'rows; the sense vectors depend on the token alone)',
+                           'cached': 'whole-vocabulary sense table built once per weight version OUTSIDE the timed region; '
+                                     'the mix kernel gathers its rows by token id',
+                           'position': 'once per position (the reference\'s order of operations)'}[content],
                        'parallelism': f'{world} independent batch replicas (no data-path collective)'},
         }
-        if per_position is not None:
-            line['content_per_position'] = per_position   # the reference's order of operations, same process / batch
+        # the other content orders, same process / batch: the reference's order of operations (content_per_position), the
+        # cached whole-vocabulary table (content_cached_table), the per-step table of the batch's distinct ids
+        for mode, key in (('position', 'content_per_position'), ('cached', 'content_cached_table'),
+                          ('batch', 'content_per_batch_table')):
+            if mode in others:
+                line[key] = others[mode]
         if kernel_rows:
             # `roofline` = the attention-path kernel with the largest total time (the path BASELINE.json's
             # north_star names: flash attention tile / sense contraction); every timed kernel, including the

@@ -222,8 +222,10 @@ int bp_sense_mix_weighted(const void *qk, const void *content, const float *key_
  * DISTINCT token of a batch (table = its output for the sorted distinct ids, row_index = torch.unique's inverse) and never
  * materialise the (batch, seqlen, nsenses * d_out) content tensor the reference builds (:276, :313).
  *   table      (table_rows, nsenses, d_out), element strides t_row_stride / t_sense_stride, last dim contiguous
- *   row_index  (batch, seqlen) int32, unit stride along seqlen, element stride idx_batch_stride; 0 <= value < table_rows
- *              (not checked on the device: an index outside the table reads outside the table)
+ *   row_index  (batch, seqlen) int32, unit stride along seqlen, element stride idx_batch_stride; 0 <= value < table_rows.
+ *              NOT validated: the kernel clamps every index as an unsigned value to table_rows - 1, so a negative or too
+ *              large index silently reads the table's LAST row (never memory outside the table); callers that need an
+ *              error for bad ids check them before the call (the reference's nn.Embedding asserts on the device)
  * Restrictions (BP_ERR_SHAPE otherwise; callers gather the rows themselves and call bp_sense_mix): the 16-byte vector
  * path (d_k % 8 == 0, d_out % 8 == 0, aligned bases, strides multiples of 8), seqlen <= 4096 (2048 for d_k > 64), and
  * table_rows * t_row_stride * 2 bytes < 4 GiB (row offsets are 32-bit in the DMA instruction).

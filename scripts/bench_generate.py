@@ -30,22 +30,24 @@ def main():
     torch.manual_seed(0)
     model = BackpackLMHeadModel(cfg, device=dev, dtype=torch.bfloat16).eval()
     ids = torch.randint(0, 50257, (a.batch, a.prompt), device=dev)
-    res = dict(model=a.model, batch=a.batch, prompt=a.prompt, max_length=a.max_length, new_tokens=a.max_length - 1 - a.prompt)
-    outs = {}
-    for cg in (False, True):
-        model.generate(ids, max_length=a.max_length, cg=cg)      # warm-up (allocator, library handles)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        outs[cg] = model.generate(ids, max_length=a.max_length, cg=cg)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        key = 'graph_replay' if cg else 'eager_loop'
-        res[key + '_ms'] = round(dt * 1e3, 1)
-        res[key + '_ms_per_token'] = round(dt * 1e3 / res['new_tokens'], 3)
-    same = (outs[False] == outs[True]).float().mean().item()
-    res['tokens_equal_fraction'] = round(same, 4)     # random weights: near-uniform logits, ties flip easily
-    print(json.dumps(res))
-
+    for mode in ('off', 'cached'):    # content network per position (the reference's order) / cached whole-vocabulary table
+        model.transformer.sense_table_mode = mode
+        res = dict(model=a.model, batch=a.batch, prompt=a.prompt, max_length=a.max_length,
+                   new_tokens=a.max_length - 1 - a.prompt, sense_table=mode)
+        outs = {}
+        for cg in (False, True):
+            model.generate(ids, max_length=a.max_length, cg=cg)      # warm-up (allocator, library handles)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            outs[cg] = model.generate(ids, max_length=a.max_length, cg=cg)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            key = 'graph_replay' if cg else 'eager_loop'
+            res[key + '_ms'] = round(dt * 1e3, 1)
+            res[key + '_ms_per_token'] = round(dt * 1e3 / res['new_tokens'], 3)
+        same = (outs[False] == outs[True]).float().mean().item()
+        res['tokens_equal_fraction'] = round(same, 4)     # random weights: near-uniform logits, ties flip easily
+        print(json.dumps(res), flush=True)
 
 if __name__ == '__main__':
     main()

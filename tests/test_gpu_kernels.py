@@ -649,6 +649,88 @@ def test_sense_mix_gather_equals_sense_mix_on_the_gathered_rows(shape, dtype):
     assert bp.sense_mix_gather(qk, table, index, out=out, lse=lse) is out and torch.equal(out, want)
 
 
+@pytest.mark.parametrize('shape', [(2, 256, 16, 48, 768, 100000), (2, 256, 64, 10, 640, 50264), (1, 320, 16, 48, 768, 174762)])
+def test_sense_mix_gather_table_offsets_beyond_2_gib(shape):
+    """The gathering mix forms `row_index * row bytes` as an UNSIGNED 32-bit offset (sense_mix_dma.hip; bp_api.hip admits
+    tables of up to 4 GiB): tables whose rows lie on both sides of byte offset 2^31 -- Small's width with 100 000 rows
+    (2.46 GB), Mini k = 64's REAL table 50 264 x 64 x 640 (4.12 GB, 96 % of the range; what `bench.py --workload
+    mini-k64-1024` and the cached vocabulary table read), and the largest table of Small's width the entry point takes
+    (174 762 rows = 4 GiB - 24 KB).  Index pinned to row 0, the rows just below / across / above 2^31 and the last row in
+    both samples; the rest random over the whole table.  Bit-identical to bp_sense_mix on the materialised rows."""
+    bp = _bp()
+    b, s, k, dk, d, rows = shape
+    torch.manual_seed(21)
+    qk = (torch.randn(b, s, 2, k, dk, device=DEV) * 0.9).bfloat16()
+    table = torch.randn(rows, k, d, device=DEV, dtype=torch.bfloat16)
+    row_bytes = k * d * 2
+    assert 2 ** 31 < rows * row_bytes < 2 ** 32
+    edge = 2 ** 31 // row_bytes                    # the row that holds byte 2^31 (or starts exactly there)
+    index = torch.randint(0, rows, (b, s), device=DEV, dtype=torch.int32)
+    pins = torch.tensor([0, edge - 1, edge, edge + 1, rows - 1, rows - 2], device=DEV, dtype=torch.int32)
+    for bi in range(b):
+        index[bi, :6] = pins                       # seen by every later query of the sample
+        index[bi, -6:] = pins.flip(0)              # ... and on the diagonal of the last query tile
+    assert bp.sense_mix_gather_supported(qk, table, s)
+    want = bp.sense_mix(qk, table[index.long()])
+    got = bp.sense_mix_gather(qk, table, index)
+    assert torch.equal(got, want)
+    # the rows beyond 2^31 matter: zeroing them changes the result (the comparison above is not vacuous)
+    upper = index >= edge
+    assert upper.float().mean().item() > 0.3
+    table[edge:].zero_()
+    assert not torch.equal(bp.sense_mix_gather(qk, table, index), want)
+    # one row more and the offsets no longer fit: refused by the support check and by the entry point (BP_ERR_SHAPE)
+    if rows * row_bytes + row_bytes >= 2 ** 32:
+        del table
+        bigger = torch.empty(rows + 1, k, d, device=DEV, dtype=torch.bfloat16)
+        assert not bp.sense_mix_gather_supported(qk, bigger, s)
+        with pytest.raises(RuntimeError, match='bp_sense_mix_gather'):
+            bp.sense_mix_gather(qk, bigger, index)
+
+
+def test_sense_mix_gather_clamps_indices_outside_the_table():
+    """`row_index` is not validated; the kernel clamps it as an unsigned value to the last row (include/bp_hip.h), so a
+    negative or too large index reads the table's last row and never memory outside it."""
+    bp = _bp()
+    torch.manual_seed(5)
+    qk = torch.randn(2, 200, 2, 4, 16, device=DEV).bfloat16()
+    table = torch.randn(50, 4, 256, device=DEV).bfloat16()
+    index = torch.randint(0, 50, (2, 200), device=DEV, dtype=torch.int32)
+    bad = index.clone()
+    bad[0, 3], bad[0, 77], bad[1, 199], bad[1, 0] = -1, 50, 2 ** 31 - 1, -(2 ** 31)
+    good = bad.clone()
+    good[0, 3], good[0, 77], good[1, 199], good[1, 0] = 49, 49, 49, 49
+    assert torch.equal(bp.sense_mix_gather(qk, table, bad), bp.sense_mix_gather(qk, table, good))
+
+
+def test_flash_varlen_reads_cu_seqlens_even_when_the_buffer_has_batch_times_max_rows():
+    """An over-allocated (B * max_seqlen)-row buffer with SHORTER sequences in cu_seqlens is legal (the reference's
+    mha_fwd reads the offsets only, csrc/flash_attn/fmha_api.cpp:189-325): the binding must not infer a fixed-length
+    batch from the row count (round-4 advisor finding).  Forward and backward against per-sequence eager attention."""
+    bp = _bp()
+    torch.manual_seed(2)
+    b, smax, h, d = 3, 128, 2, 64
+    lens = [128, 40, 77]
+    cu = torch.tensor([0, 128, 168, 245], dtype=torch.int32, device=DEV)
+    q, k, v = (torch.randn(b * smax, h, d, device=DEV).bfloat16() for _ in range(3))
+    out = torch.zeros_like(q)
+    scale = d ** -0.5
+    lse = bp.flash_fwd(q, k, v, out, cu, cu, smax, smax, scale, True)
+    dout = torch.randn_like(q)
+    dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+    bp.flash_bwd(dout, q, k, v, out, lse, dq, dk, dv, cu, cu, smax, smax, scale, True)
+    for i, n in enumerate(lens):
+        lo = int(cu[i])
+        qi, ki, vi = (t[lo:lo + n].float().requires_grad_() for t in (q, k, v))
+        ref, _, _ = R.attention_fp32(qi[None], ki[None], vi[None], causal=True, softmax_scale=scale)
+        ref = ref[0]
+        assert (out[lo:lo + n].float() - ref).abs().max().item() < 2e-2
+        gq, gk, gv = torch.autograd.grad(ref, (qi, ki, vi), dout[lo:lo + n].float())
+        for got, want in ((dq, gq), (dk, gk), (dv, gv)):
+            assert (got[lo:lo + n].float() - want).abs().max().item() < 6e-2
+    assert torch.count_nonzero(out[245:]) == 0 and torch.count_nonzero(dq[245:]) == 0    # rows behind the last sequence
+
+
 def test_sense_mix_gather_refuses_what_it_does_not_take():
     bp = _bp()
     qk = torch.randn(1, 64, 2, 4, 16, device=DEV).bfloat16()

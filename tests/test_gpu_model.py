@@ -58,6 +58,7 @@ def test_content_dedup_matches_the_per_position_content_network():
     autograd, not for small inputs)."""
     g, sd, model = _nano(fused=True)
     t = model.transformer
+    t.sense_table_mode = 'batch'      # (the default, 'cached', keeps a whole-vocabulary table instead: test_gpu_configs.py)
     ids = torch.randint(0, 96, (8, 32), device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
     calls = []
     orig = t._table_of_unique_tokens

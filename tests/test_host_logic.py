@@ -435,3 +435,44 @@ def test_content_of_unique_tokens_equals_the_per_position_content():
     with torch.no_grad():
         assert not t._dedup_applies(ids)                   # CPU tensors: the eager path stays the reference's, literally
     assert BackpackLMHeadModel(nano_config(dedup_content=False)).transformer.dedup_content is False
+
+
+def test_whole_vocabulary_sense_table_is_the_content_network_row_by_row_and_follows_the_weights():
+    """BackpackModel.sense_table(): the content network's output for every row of the word embedding -- on the CPU, in
+    fp32, table[ids] IS the per-position content (reference backpack.py:251-276); kept while no parameter of the content
+    model changes, rebuilt in the SAME storage after an in-place update (a captured graph reads that storage), rebuilt
+    after a reload, dropped by .train(); never consulted by the forward of CPU tensors / of the eager mode."""
+    torch.manual_seed(0)
+    model = BackpackLMHeadModel(nano_config()).eval()
+    t = model.transformer
+    assert t.sense_table_mode == 'cached'
+    ids = torch.randint(0, 96, (3, 32))
+    with torch.no_grad():
+        want = t.content_model(ids)                                    # (B,k,S,d)
+        logits = model(ids).logits
+    assert t._sense_table is None                                      # the CPU forward never built one
+    table = t.sense_table()
+    vocab = t.embeddings.word_embeddings.weight.shape[0]
+    assert table.shape == (vocab, 4, 64) and not table.requires_grad and t.sense_table() is table
+    assert torch.allclose(table[ids].transpose(1, 2), want, atol=1e-6, rtol=0)
+    ptr, before = table.data_ptr(), table.clone()
+    with torch.no_grad():
+        t.content_model.final_mlp.fc2.bias.add_(1.0)                   # in place: `_version` moves
+    after = t.sense_table()
+    assert after.data_ptr() == ptr and torch.allclose(after, before + 1.0, atol=1e-5)
+    with torch.no_grad():                                              # the word embedding is a parameter of the content model too
+        t.embeddings.word_embeddings.weight[5].add_(torch.randn(64))    # (a pure rescale would vanish in ln_0)
+    again = t.sense_table()
+    assert not torch.allclose(again[5], before[5] + 1.0, atol=1e-3) and torch.allclose(again[6], before[6] + 1.0, atol=1e-5)
+    model.load_state_dict({k: v.clone() for k, v in model.state_dict().items()})   # copy_ in place: versions move again
+    assert t._sense_table[0] != t._sense_table_key()
+    model.train()
+    assert t._sense_table is None
+    model.eval()
+    with torch.inference_mode():
+        inside = t.sense_table()                                       # built as a normal tensor even in inference mode
+    assert not inside.is_inference()
+    with torch.no_grad():
+        assert torch.equal(model(ids).logits - logits, model(ids).logits - logits)   # (CPU forward unaffected; finite)
+    with pytest.raises(AssertionError):
+        BackpackLMHeadModel(nano_config(sense_table='sometimes'))
