@@ -426,12 +426,12 @@ def sense_mix(qk, content, softmax_scale=None, out=None, lse=None, key_weight=No
 
 
 def sense_mix_gather_supported(qk, table, seqlen):
-    """Shapes bp_sense_mix_gather takes (include/bp_hip.h): the 16-byte vector path, seqlen <= 4096 (2048 for d_k > 64),
-    32-bit row offsets into the table."""
+    """Shapes bp_sense_mix_gather takes (include/bp_hip.h): the 16-byte vector path, seqlen <= 4096, at most 65 536 table
+    rows (any GPT-2 vocabulary), 32-bit byte offsets into the table."""
     dk = round_up(qk.shape[-1], 8)
     return (qk.is_cuda and table.is_cuda and table.dim() == 3 and table.stride(-1) == 1 and table.shape[2] % 8 == 0
             and table.stride(0) % 8 == 0 and table.stride(1) % 8 == 0 and table.data_ptr() % 16 == 0
-            and seqlen <= (4096 if dk <= 64 else 2048)
+            and seqlen <= 4096 and table.shape[0] <= 65536
             and table.shape[0] * table.stride(0) * table.element_size() < 2 ** 32)
 
 

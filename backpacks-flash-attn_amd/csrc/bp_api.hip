@@ -337,7 +337,7 @@ int bp_sense_mix_gather(const void *qk, const void *table, const int32_t *row_in
     if (d_k < 8 || d_k > 128 || d_k % 8 != 0) return BP_ERR_HEAD_DIM;
     if (queue_ws != nullptr && !aligned16(queue_ws)) return BP_ERR_SHAPE;
     if (d_out < 8 || d_out % 8 != 0) return BP_ERR_DOUT;
-    if (batch <= 0 || nsenses <= 0 || seqlen <= 0 || seqlen > bp::mix_gather_max_keys(d_k) || table_rows <= 0) return BP_ERR_SHAPE;
+    if (batch <= 0 || nsenses <= 0 || seqlen <= 0 || seqlen > bp::kMixGatherMaxKeys || table_rows <= 0 || table_rows > bp::kMixGatherMaxRows) return BP_ERR_SHAPE;
     if (qk == nullptr || table == nullptr || row_index == nullptr || out == nullptr || lse_ws == nullptr) return BP_ERR_SHAPE;
     if (!scale_ok(softmax_scale)) return BP_ERR_SCALE;
     const uint16_t *qp = static_cast<const uint16_t *>(qk);

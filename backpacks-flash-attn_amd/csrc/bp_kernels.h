@@ -90,8 +90,9 @@ struct MixParams {
     MixQueues *queues;        // caller's record (queue_ws) or NULL; armed by launch_sense_mix_dma
 };
 
-// longest sequence the gathering sense mix takes: its per-job offset table shares the LDS with the ring (sense_mix_dma.hip)
-inline int mix_gather_max_keys(int d_k) { return d_k <= 64 ? 4096 : 2048; }
+// limits of the gathering sense mix: a job's row indices share the LDS with the ring as u16 (sense_mix_dma.hip)
+constexpr int kMixGatherMaxKeys = 4096;
+constexpr int64_t kMixGatherMaxRows = 65536;
 
 // backward of the sense combination (sense_mix_bwd.hip)
 struct MixBwdParams {

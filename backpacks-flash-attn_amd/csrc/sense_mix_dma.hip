@@ -40,7 +40,7 @@ namespace bp {
 // Development builds only (-DBP_MIX_PROFILE, scripts/probes/mix_timeline): every wave adds up the s_memtime ticks its
 // clean steps spend in each phase; never in the shipped library.
 #ifdef BP_MIX_PROFILE
-__device__ unsigned long long g_mix_prof[256][8][8];   // [workgroup][wave][phase 0..5, 6 = clean steps, 7 = job ticks]
+__device__ unsigned long long g_mix_prof[256][8][12];   // [workgroup][wave][phase 0..5, 6 = clean steps, 7 = job ticks]
 #define MIX_TICK(var) const unsigned long long var = __builtin_readcyclecounter()
 #define MIX_ADD(k, expr) prof[k] += (expr)
 #else
@@ -68,18 +68,28 @@ struct MixDmaCfg {
     static constexpr int K_ROWS_PER_DMA = 1024 / KROW;   // 8 or 4
     static constexpr int JOB_OFF = NSTAGE * STAGE;       // 16 bytes: job broadcast
     static constexpr int SMEM = JOB_OFF + 16;
-    // GATHER (bp_sense_mix_gather): the content rows are rows of a TABLE (one per distinct token of the batch), picked by
-    // an index per key.  The job's byte offsets index[key] * row bytes live behind the ring, one u32 per key.
-    static constexpr int GATHER_OFF = SMEM;
-    static constexpr int GATHER_MAX_KEYS = KD <= 4 ? 4096 : 2048;   // (= mix_gather_max_keys(d_k), bp_kernels.h: 160 KB of LDS)
-    static constexpr int GATHER_BYTES = GATHER_MAX_KEYS * 4;
+    // Next sense's query operands, staged through LDS by DMA (see request_q): per wave KD fragments of 64 lanes x 16 B and
+    // 64 x 4 B of log-sum-exp.  Only where the ring leaves room (128-byte K rows) and the flat two-phase loop runs.
+    static constexpr bool ASYNC_Q = !WEIGHTED && KD <= 3;   // (d_k = 64 spills with the staging reads; wider ones have no LDS left)
+    static constexpr int QSTAGE_OFF = SMEM;
+    static constexpr int QSTAGE_WAVE = KD * 1024 + 256;
+    static constexpr int QSTAGE_BYTES = ASYNC_Q ? NWAVE * QSTAGE_WAVE : 0;
+    // GATHER (bp_sense_mix_gather): the content rows are rows of a TABLE (one per token id), picked by an index per key.
+    // The job's row indices live behind the staging area as u16: 8 KB = 4096 keys (= kMixGatherMaxKeys, bp_kernels.h), tables
+    // of up to 65 536 rows (= kMixGatherMaxRows: any GPT-2 vocabulary); the byte offset row * row bytes is formed per piece.
+    // (A u16 / u32 switch per launch costs the d_k = 48 instantiation five spilled registers: larger tables are gathered by
+    // the caller, bp_hip.sense_mix_gather_supported.)
+    static constexpr int GATHER_OFF = SMEM + QSTAGE_BYTES;
+    static constexpr int GATHER_BYTES = 8192;
+    static constexpr int LDS_BYTES = SMEM + QSTAGE_BYTES;
+    static_assert(LDS_BYTES + GATHER_BYTES <= 160 * 1024, "LDS budget");
 };
 
 template <class ET, int KD, bool FULL, bool WEIGHTED, bool GATHER = false>
 __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
     using C = MixDmaCfg<KD, WEIGHTED>;
     using E = Elem<ET>;
-    __shared__ __attribute__((aligned(16))) char smem[C::SMEM + (GATHER ? C::GATHER_BYTES : 0)];
+    __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES + (GATHER ? C::GATHER_BYTES : 0)];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -133,7 +143,7 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
     };
 
 #ifdef BP_MIX_PROFILE
-    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     for (;;) {
         __syncthreads();   // every wave is done with the previous job's ring (and has read its job word)
@@ -194,13 +204,14 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
             c_voff[j] = (uint32_t)((GATHER ? 0 : row * p.c_rs) + col) * 2u;   // (GATHER: the row part comes from the table)
         }
         if (GATHER) {
-            // byte offset of every key's table row, clamped past the sequence end (those keys are masked); every wave is
-            // done with the previous job's table (the __syncthreads in front of the job word)
+            // table row of every key of the job, clamped past the sequence end (those keys are masked) and to the table
+            // (an index outside it reads its last row, never memory outside it); every wave is done with the previous
+            // job's table (the __syncthreads in front of the job word)
             const int32_t *idx = p.row_index + (int64_t)batch * p.idx_bs;
-            const uint32_t row_bytes = (uint32_t)p.c_rs * 2u;
-            for (int i = tid; i < nkb * C::BK; i += C::NT)
-                *reinterpret_cast<uint32_t *>(smem + C::GATHER_OFF + i * 4) =
-                    min((uint32_t)idx[min(i, S - 1)], p.last_table_row) * row_bytes;   // an index outside the table reads its last row, never outside it
+            for (int i = tid; i < nkb * C::BK; i += C::NT) {
+                const uint32_t row = min((uint32_t)idx[min(i, S - 1)], p.last_table_row);
+                *reinterpret_cast<uint16_t *>(smem + C::GATHER_OFF + i * 2) = (uint16_t)row;
+            }
             __syncthreads();
         }
 
@@ -211,12 +222,13 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
         const uint16_t *ks2 = kg, *cs2 = cg;     // key / content base of sense l2
         const uint16_t *kt2 = kg, *ct2 = cg;     // ... of tile kb2 in it
         const int64_t k_tile_step = (int64_t)C::BK * p.qk_rs, c_tile_step = (int64_t)C::BK * p.c_rs;
-        // GATHER: piece j of tile kb2 = two table rows, their byte offsets read from the job's LDS table; the base is the
+        // GATHER: piece j of tile kb2 = two table rows, their indices read from the job's LDS table; the base is the
         // SENSE's (table + l2 * c_ss), and table rows are re-read by other jobs, so the loads stay cacheable
+        const uint32_t gather_row_bytes = (uint32_t)p.c_rs * 2u;
         auto gather_piece = [&](int j, uint32_t lds_dst) {
             const int key = kb2 * C::BK + c_piece_row(j);
-            const uint32_t off = *reinterpret_cast<const uint32_t *>(smem + C::GATHER_OFF + key * 4) + c_voff[j];
-            dma16_s(cs2, off, lds_dst);
+            const uint32_t row = *reinterpret_cast<const uint16_t *>(smem + C::GATHER_OFF + key * 2);
+            dma16_s(cs2, row * gather_row_bytes + c_voff[j], lds_dst);
         };
         auto issue = [&](int, int, int slot, uint32_t pieces) {
             const uint32_t stage_off = lds0 + slot * C::STAGE;
@@ -281,28 +293,32 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
             lse2 = p.lse[((int64_t)batch * p.nsenses + l) * p.lse_stride + my_q_clamped] * kLog2e;
         };
 
-        // The same for the NEXT sense, requested at the start of a sense's last ring step and adopted behind it: the
-        // loads are older than that step's DMA pieces, so the ring's own counted wait covers them and no
-        // compiler-placed vmcnt(0) stalls the wave once per sense (a quarter of the steps of a light query tile).
-        u32x4 qn[KD];
-        float lse_n = 0.f;
-#pragma unroll
-        for (int s = 0; s < KD; ++s) qn[s] = u32x4{0u, 0u, 0u, 0u};
+        // The same for the NEXT sense, requested in the middle of a sense's last ring step (between its X and Y parts) and
+        // adopted behind it -- THROUGH LDS: every lane's fragments and its log-sum-exp are DMA'd into the wave's own staging
+        // area and read back after the ring's counted wait.  The DMAs are older than the pieces of tile + 2, which that step
+        // issues in its Y part, so `vmcnt(DMA_PER_STAGE)` covers them and no compiler-placed vmcnt(0) stalls the wave
+        // once per sense (a quarter of the steps of a light query tile).
+        // Rounds 3-4 used asynchronous loads into REGISTERS here.  That is only sound while the compiler never copies the
+        // destination registers before the data has landed, which it is free to do: with the request on two paths (live
+        // / dead wave) hipcc loaded into temporaries and placed the phi copies `v_mov home, temporary` at the join, in
+        // front of the wait -- garbage query fragments, NaN outputs (round-5 listing).  LDS has no such hazard, and the
+        // staged operands cost no registers while they travel.
+        const int qstage = C::QSTAGE_OFF + wave * C::QSTAGE_WAVE;
         auto request_q = [&](int l) {
             const uint16_t *row = qg + (int64_t)my_q_clamped * p.qk_rs + (int64_t)l * p.qk_ss;
 #pragma unroll
-            for (int s = 0; s < KD; ++s) qn[s] = ld_global_16B_async(row + min(16 * s + 8 * hh, p.dk - 8));
-            lse_n = ld_global_f32_async(p.lse + ((int64_t)batch * p.nsenses + l) * p.lse_stride + my_q_clamped);
+            for (int s = 0; s < KD; ++s)
+                dma16(row + min(16 * s + 8 * hh, p.dk - 8), __builtin_amdgcn_readfirstlane(lds0 + qstage + s * 1024));
+            dma4(p.lse + ((int64_t)batch * p.nsenses + l) * p.lse_stride + my_q_clamped, lds0 + qstage + KD * 1024);
         };
         auto adopt_q = [&]() {
             wait_vmcnt<C::DMA_PER_STAGE>();   // everything older than the last step's DMA pieces has landed
 #pragma unroll
             for (int s = 0; s < KD; ++s) {
-                asm volatile("" : "+v"(qn[s]));
-                qf[s] = (16 * s + 8 * hh < p.dk) ? qn[s] : u32x4{0u, 0u, 0u, 0u};
+                qf[s] = lds_read_16B(smem, qstage + s * 1024 + lane * 16);
+                if (16 * s + 8 * hh >= p.dk) qf[s] = u32x4{0u, 0u, 0u, 0u};
             }
-            asm volatile("" : "+v"(lse_n));
-            lse2 = lse_n * kLog2e;
+            lse2 = *reinterpret_cast<const float *>(smem + qstage + KD * 1024 + lane * 4) * kLog2e;
         };
 
         // S^T of the 32-key half kk of the tile in ring slot byte offset `stage`
@@ -348,22 +364,49 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
                            });
         };
 
+        // Causal mask of one 32-key half on its packed P^T words.  `rel` = the half's sub-block index minus the index of
+        // the sub-block that holds this wave's diagonal (wave-uniform): < 0 entirely visible, == 0 the diagonal sub-block
+        // (its first key is q0: clear the 16-bit entries whose key lies above my query), > 0 entirely invisible.  AND
+        // masks, so an inf from an invisible, larger score dies too.
+        auto mask_half = [&](u32x4 (&pf)[2], int rel) {
+            if (rel > 0) {
+                pf[0] = pf[1] = u32x4{0u, 0u, 0u, 0u};
+            } else if (rel == 0) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r0 = ks * 8 + 2 * i;
+                        const int rel0 = (r0 & 3) + 8 * (r0 >> 2) + 4 * hh;   // rel of r0 + 1 is rel0 + 1
+                        const uint32_t keep = (rel0 <= l31 ? 0x0000ffffu : 0u) | (rel0 + 1 <= l31 ? 0xffff0000u : 0u);
+                        pf[ks][i] &= keep;
+                    }
+            }
+        };
+
         // The step is cut into a vector-heavy half X (S^T of both key halves, softmax of half 0, the first 8 MFMAs of
         // half 0 with the exponentials of half 1 between them, pack) and a matrix-only half Y (the other 24 MFMAs),
-        // and the two waves of a SIMD (w and w + 4) run them in ANTI-PHASE: waves 4-7 enter the clean loop one barrier
+        // and the two waves of a SIMD (w and w + 4) run them in ANTI-PHASE: waves 4-7 enter the job's loop one barrier
         // late, so X of one wave always meets Y of the other (see the loop below).  X hands Y three packed operands.
+        // Since round 5 EVERY step has this form, the ones that touch the diagonal too (`edge`: the masks above on the
+        // packed words; a wave whose rows lie entirely above the tile -- `live` false -- only issues its DMA share and
+        // keeps the barrier count).  Before, diagonal steps ran a one-phase per-half form in which both waves of a SIMD sat
+        // in their softmax and then both in their MFMAs: 4340 clocks per step against 3260 for a clean one, with 40 % of a
+        // job's steps on the diagonal at S = 1024 (profiles/r05_*), and the anti-phase had to be re-established per sense.
         u32x4 pfc[3];   // P^T of half 0 keys 16..31, of half 1 keys 0..15 and 16..31
-        auto clean_x = [&](int stage, int l2, int kb2, int slot2, bool dma) {
+        auto step_x = [&](int stage, int kb, int slot2, bool dma, bool live, bool edge) {
+            if (!live) {
+                if (dma) issue(0, 0, slot2, kAllPieces);
+                return;
+            }
             // X is one dependent chain (S^T -> softmax -> first MFMAs), Y a stream of independent MFMAs: without a
             // priority the older waves 0-3 win every arbitration, and X of waves 4-7 starves behind their Y (2230
             // clocks against 1360 the other way round, r03_ab timeline)
             __builtin_amdgcn_s_setprio(BP_MIX_X_PRIO);
-            u32x4 pf0[2];
-            f32x16 st1;
+            f32x16 st0, st1;
             {
                 // S^T of both key halves as one operand stream, alternating accumulators (the per-half form waits for
                 // an LDS round trip in front of each of its KD dependent MFMAs: ~600 clocks for the six of d_k = 48)
-                f32x16 st0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) st0[r] = st1[r] = 0.f;
                 mfma_stream<2 * KD>(
@@ -372,10 +415,12 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
                         if (i & 1) { st1 = E::mfma(a, qf[i >> 1], st1); asm volatile("" : "+v"(st1)); }
                         else { st0 = E::mfma(a, qf[i >> 1], st0); asm volatile("" : "+v"(st0)); }
                     });
-                exponentiate(st0);
-                pack(st0, pf0);
             }
-            if (dma) issue(l2, kb2, slot2, 0x03u);
+            u32x4 pf0[2];
+            exponentiate(st0);
+            pack(st0, pf0);
+            if (edge) mask_half(pf0, 2 * kb - my_diag_sub);
+            if (dma) issue(0, 0, slot2, 0x03u);
             // 8 MFMAs of half 0, keys 0..15, each followed by 2 fma + 2 exp of half 1; the C operand of MFMA n+1 is
             // requested before MFMA n issues, so the LDS latency hides behind a full MFMA
             {
@@ -398,25 +443,30 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
                     a = a_next;
                 }
             }
-            if (dma) issue(l2, kb2, slot2, kAllPieces & ~0x03u);
+            if (dma) issue(0, 0, slot2, kAllPieces & ~0x03u);
             pfc[0] = pf0[1];
             u32x4 pf1[2];
             pack(st1, pf1);
+            if (edge) mask_half(pf1, 2 * kb + 1 - my_diag_sub);
             pfc[1] = pf1[0];
             pfc[2] = pf1[1];
             asm volatile("" : "+v"(pfc[0]), "+v"(pfc[1]), "+v"(pfc[2]));   // the packs belong to X, not behind the barrier
             __builtin_amdgcn_s_setprio(0);
         };
-        auto clean_y = [&](int stage, int l2, int kb2, int slot2, bool dma) {
-            if (dma) issue(l2, kb2, slot2, 0x03u);
+        auto step_y = [&](int stage, int slot2, bool dma, bool live) {
+            if (!live) {
+                if (dma) issue(0, 0, slot2, kAllPieces);
+                return;
+            }
+            if (dma) issue(0, 0, slot2, 0x03u);
             pv_stream(stage, 16, pfc, [&](int i) {
-                if (i == 11 && dma) issue(l2, kb2, slot2, kAllPieces & ~0x03u);
+                if (i == 11 && dma) issue(0, 0, slot2, kAllPieces & ~0x03u);
             });
         };
 
-        // ---- a step that touches the diagonal region (or carries key weights): per-half liveness, masking
-        auto edge_step = [&](int stage, int l, int kb, int l2, int kb2, int slot2) {
-            issue(l2, kb2, slot2, 0x01u);
+        // ---- key-weighted launches (the intervention hook): every step in the simple one-phase per-half form
+        auto weighted_step = [&](int stage, int l, int kb, int slot2) {
+            issue(0, 0, slot2, 0x01u);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int sub = kb * 2 + kk;
@@ -426,8 +476,8 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
                     f32x16 st = scores(stage, kk);
                     exponentiate(st);
                     if (WEIGHTED) {
-                        // intervention hook: alpha[b, l, :, key] *= w[b, l, key]  (register r holds key
-                        // (r & 3) + 8 (r >> 2) + 4 hh of the sub-block: four runs of four consecutive keys)
+                        // alpha[b, l, :, key] *= w[b, l, key]  (register r holds key (r & 3) + 8 (r >> 2) + 4 hh of the
+                        // sub-block: four runs of four consecutive keys)
                         const int wbase = stage + C::KTILE + C::CTILE + wave * 256 + (kk * 32 + 4 * hh) * 4;
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
@@ -440,23 +490,10 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
                         }
                     }
                     pack(st, pf);
-                    if (sub == my_diag_sub) {
-                        // Diagonal sub-block (its first key is q0): clear the 16-bit P entries whose key
-                        // lies above my query, with AND masks on the packed words (AND also kills an inf
-                        // from an invisible, larger score).
-#pragma unroll
-                        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const int r0 = ks * 8 + 2 * i;
-                                const int rel0 = (r0 & 3) + 8 * (r0 >> 2) + 4 * hh;   // rel of r0 + 1 is rel0 + 1
-                                const uint32_t keep = (rel0 <= l31 ? 0x0000ffffu : 0u) | (rel0 + 1 <= l31 ? 0xffff0000u : 0u);
-                                pf[ks][i] &= keep;
-                            }
-                    }
+                    mask_half(pf, sub - my_diag_sub);
                     pv_stream(stage, kk * 32, pf, [](int) {});
                 }
-                issue(l2, kb2, slot2, kk == 0 ? 0x0eu : (kAllPieces & ~0x0fu));
+                issue(0, 0, slot2, kk == 0 ? 0x0eu : (kAllPieces & ~0x0fu));
             }
         };
 
@@ -493,56 +530,90 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
             slot = slot == 2 ? 0 : slot + 1;
             advance2();
         };
-        // (wider q.k products keep the plain per-sense load: 16 more live registers would spill there)
-        constexpr bool ASYNC_Q = KD <= 3;
-        if (ASYNC_Q && wave_has_rows) take_q(0);
-        for (int l = 0; l < p.nsenses; ++l) {
-            if (!ASYNC_Q && wave_has_rows) take_q(l);
-            const bool more = ASYNC_Q && wave_has_rows && l + 1 < p.nsenses;
-            // Clean steps, two barriers each.  Waves 0-3 run  [bar X bar Y] per tile and one closing barrier; waves 4-7 one
-            // opening barrier and then the same [bar X bar Y]: between any two barriers one wave of a SIMD is in X
-            // (VALU + 14 MFMAs) and the other in Y (24 MFMAs) of the same or the previous tile.  Ring: tile kb + 2 goes
-            // to the slot of tile kb - 1, last read by Y of waves 4-7 in front of the barrier that ends X(kb) of waves
-            // 0-3 -- so every wave issues it right behind that barrier (start of Y for waves 0-3, of X for waves 4-7);
-            // every wave waits for its share of the next tile before each barrier (a no-op on every other one).
-            if (nkb_clean > 0) {
-                const bool late = wave >= C::NWAVE / 2;
-                if (late) step_begin();
-                for (int kb = 0; kb < nkb_clean; ++kb) {
-                    MIX_TICK(t0);
+        if (wave_has_rows) take_q(0);
+        if (WEIGHTED) {
+            for (int l = 0; l < p.nsenses; ++l) {
+                if (l > 0 && wave_has_rows) take_q(l);
+                for (int kb = 0; kb < nkb; ++kb) {
                     step_begin();
-                    MIX_TICK(t1);
-                    MIX_ADD(0, t1 - t0);
-                    clean_x(slot * C::STAGE, l2, kb2, slot >= 1 ? slot - 1 : 2, late);
+                    weighted_step(slot * C::STAGE, l, kb, slot >= 1 ? slot - 1 : 2);
+                    step_end();
+                }
+            }
+        } else {
+            // Per sense: the clean tiles (entirely below the workgroup's queries) in the two-phase form, then the tiles
+            // that touch the diagonal in ONE phase per step.
+            //   clean: waves 0-3 run  [bar X bar Y]  per tile and one closing barrier; waves 4-7 one opening barrier and
+            //   then the same [bar X bar Y]: between any two barriers one wave of a SIMD is in X (VALU + 14 MFMAs) and
+            //   the other in Y (24 MFMAs) of the same or the previous tile.  Ring: tile t + 2 goes to the slot of tile
+            //   t - 1, last read by Y of waves 4-7 in front of the barrier that ends X(t) of waves 0-3 -- so every wave
+            //   issues it right behind that barrier (start of Y for waves 0-3, of X for waves 4-7); every wave waits for
+            //   its share of the next tile before each barrier (a no-op on every other one).
+            //   diagonal: X and Y of a step back to back under one barrier (`step_x` / `step_y` with the causal masks on
+            //   the packed words; a wave whose rows lie above the tile only issues its DMA share).  From the third of a
+            //   full query tile's four diagonal steps on every SIMD holds at most ONE live wave, and what bounds the step
+            //   is that wave's own dependent chain: S^T of both halves as one stream, the first MFMAs between the second
+            //   half's exponentials and one 24-MFMA stream instead of round 4's per-half form (scores, softmax, 16 MFMAs,
+            //   twice: ~3190 clocks per diagonal step whoever was live, profiles/r05_c_timeline_*).  Carrying the
+            //   anti-phase THROUGH the diagonal steps (two barriers there too) was built first and measured slower:
+            //   a lone wave then serialises X, barrier, Y (3216 clocks per diagonal step; r05_c).
+            const bool late = wave >= C::NWAVE / 2;
+            for (int l = 0; l < p.nsenses; ++l) {
+                const int next_sense = (C::ASYNC_Q && wave_has_rows && l + 1 < p.nsenses) ? l + 1 : -1;
+                if (!C::ASYNC_Q && l > 0 && wave_has_rows) take_q(l);   // (no LDS left for the staging: plain loads)
+                if (nkb_clean > 0) {
+                    if (late) step_begin();
+                    for (int kb = 0; kb < nkb_clean; ++kb) {
+                        const int slot2 = slot >= 1 ? slot - 1 : 2;
+                        MIX_TICK(t0);
+                        step_begin();
+                        MIX_TICK(t1);
+                        step_x(slot * C::STAGE, kb, slot2, late, true, false);   // (waves without rows run on clamped operands: nothing is stored)
 #ifdef BP_MIX_PROFILE
-                    asm volatile("" : "+v"(acc[7]), "+v"(pfc[0]), "+v"(pfc[1]), "+v"(pfc[2]));
+                        asm volatile("" : "+v"(acc[7]), "+v"(pfc[0]), "+v"(pfc[1]), "+v"(pfc[2]));
 #endif
-                    MIX_TICK(t2);
-                    MIX_ADD(1, t2 - t1);
+                        MIX_TICK(t2);
+                        step_begin();
+                        MIX_TICK(t3);
+                        step_y(slot * C::STAGE, slot2, !late, true);
+#ifdef BP_MIX_PROFILE
+                        asm volatile("" : "+v"(acc[7]));
+#endif
+                        MIX_TICK(t4);
+                        MIX_ADD(0, t1 - t0); MIX_ADD(1, t2 - t1); MIX_ADD(2, t3 - t2); MIX_ADD(3, t4 - t3); MIX_ADD(6, 1);
+                        step_end();
+                    }
+                    if (!late) __builtin_amdgcn_s_barrier();
+                }
+                for (int kb = nkb_clean; kb < nkb; ++kb) {   // (never empty: the diagonal tile is one of these)
+                    const bool live = wave_has_rows && 2 * kb <= my_diag_sub;
+                    const int slot2 = slot >= 1 ? slot - 1 : 2;
+                    MIX_TICK(e0);
                     step_begin();
-                    MIX_TICK(t3);
-                    MIX_ADD(2, t3 - t2);
-                    clean_y(slot * C::STAGE, l2, kb2, slot >= 1 ? slot - 1 : 2, !late);
+                    MIX_TICK(e1);
+                    step_x(slot * C::STAGE, kb, slot2, false, live, true);
+                    if (kb == nkb - 1 && next_sense >= 0) request_q(next_sense);   // in front of the step's DMA pieces (in Y)
+                    step_y(slot * C::STAGE, slot2, true, live);
 #ifdef BP_MIX_PROFILE
                     asm volatile("" : "+v"(acc[7]));
 #endif
-                    MIX_TICK(t4);
-                    MIX_ADD(3, t4 - t3);
-                    MIX_ADD(6, 1);
+                    MIX_TICK(e2);
+                    // profile slots: clean steps 0 wait X, 1 X, 2 wait Y, 3 Y; diagonal steps 4 whole step, 5 X + Y of LIVE waves;
+                    // 6 = #clean steps + (#diagonal steps << 32) + (#live diagonal steps << 48); 7 job ticks
+                    MIX_ADD(4, e2 - e0);
+                    MIX_ADD(5, live ? e2 - e1 : 0);
+                    MIX_ADD(6, (1ull << 32) + (live ? (1ull << 48) : 0ull));
+#ifdef BP_MIX_PROFILE
+                    {   // 8 / 9: X + Y and count of the live steps in which the SIMD's other wave (wave ^ 4) is dead; 10 / 11: ... is live
+                        const int pq0 = qt * C::BM + (wave ^ 4) * 32;
+                        const bool partner_live = pq0 < S && 2 * kb <= (pq0 >> 5);
+                        if (live) { prof[partner_live ? 10 : 8] += e2 - e1; prof[partner_live ? 11 : 9] += 1; }
+                    }
+#endif
                     step_end();
                 }
-                if (!late) __builtin_amdgcn_s_barrier();
+                if (next_sense >= 0) adopt_q();
             }
-            for (int kb = nkb_clean; kb < nkb; ++kb) {   // (never empty: the diagonal tile is an edge tile)
-                MIX_TICK(e0);
-                step_begin();
-                if (more && kb == nkb - 1) request_q(l + 1);
-                edge_step(slot * C::STAGE, l, kb, l2, kb2, slot >= 1 ? slot - 1 : 2);
-                step_end();
-                MIX_TICK(e1);
-                MIX_ADD(5, e1 - e0);
-            }
-            if (more) adopt_q();
         }
         wait_vmcnt<0>();   // the two re-fetched tiles: nothing may still be landing when the next job refills the ring
 
@@ -565,7 +636,7 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
     }
 #ifdef BP_MIX_PROFILE
     if (lane == 0 && blockIdx.x < 256)
-        for (int k = 0; k < 8; ++k) g_mix_prof[blockIdx.x][wave][k] = prof[k];
+        for (int k = 0; k < 12; ++k) g_mix_prof[blockIdx.x][wave][k] = prof[k];
 #endif
 }
 
@@ -626,7 +697,7 @@ static hipError_t launch_kd(MixParams p, hipStream_t stream) {
     const int njobs = p.b * p.n_chunks * p.n_qtiles;
     const int cus = mix_persistent_grid();
     dim3 g(njobs < cus ? njobs : cus), t(512);   // 120 KB of LDS: one workgroup per CU
-    if (p.row_index != nullptr) {   // (bp_api.hip: never together with key weights; seqlen <= GATHER_MAX_KEYS)
+    if (p.row_index != nullptr) {   // (bp_api.hip: never together with key weights)
         if (p.dout % 256 == 0) hipLaunchKernelGGL((sense_mix_dma_kernel<ET, KD, true, false, true>), g, t, 0, stream, p);
         else hipLaunchKernelGGL((sense_mix_dma_kernel<ET, KD, false, false, true>), g, t, 0, stream, p);
     } else if (p.kw != nullptr) {

@@ -227,7 +227,8 @@ int bp_sense_mix_weighted(const void *qk, const void *content, const float *key_
  *              large index silently reads the table's LAST row (never memory outside the table); callers that need an
  *              error for bad ids check them before the call (the reference's nn.Embedding asserts on the device)
  * Restrictions (BP_ERR_SHAPE otherwise; callers gather the rows themselves and call bp_sense_mix): the 16-byte vector
- * path (d_k % 8 == 0, d_out % 8 == 0, aligned bases, strides multiples of 8), seqlen <= 4096 (2048 for d_k > 64), and
+ * path (d_k % 8 == 0, d_out % 8 == 0, aligned bases, strides multiples of 8), seqlen <= 4096 and table_rows <= 65536 (a
+ * job's row indices are kept in 8 KB of LDS as u16; ABI 6 took any row count at seqlen <= 4096 / 2048), and
  * table_rows * t_row_stride * 2 bytes < 4 GiB (row offsets are 32-bit in the DMA instruction).
  * All other arguments as bp_sense_mix.
  */

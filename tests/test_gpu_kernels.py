@@ -626,7 +626,7 @@ def test_add_layer_norm_backward_is_deterministic():
 
 @pytest.mark.parametrize('shape', [(2, 1024, 16, 48, 768, 5000), (3, 300, 4, 24, 104, 97), (1, 2048, 16, 48, 256, 50264),
                                    (2, 640, 64, 10, 640, 1000), (2, 77, 4, 16, 512, 7), (1, 2048, 4, 80, 256, 300),
-                                   (1, 4096, 4, 48, 256, 300)])
+                                   (1, 4096, 4, 48, 256, 300), (1, 2112, 4, 80, 256, 300), (1, 3000, 4, 16, 64, 65536)])
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 def test_sense_mix_gather_equals_sense_mix_on_the_gathered_rows(shape, dtype):
     """bp_sense_mix_gather (content rows read from a per-token table through a row index, ABI 6) against bp_sense_mix on the
@@ -649,13 +649,13 @@ def test_sense_mix_gather_equals_sense_mix_on_the_gathered_rows(shape, dtype):
     assert bp.sense_mix_gather(qk, table, index, out=out, lse=lse) is out and torch.equal(out, want)
 
 
-@pytest.mark.parametrize('shape', [(2, 256, 16, 48, 768, 100000), (2, 256, 64, 10, 640, 50264), (1, 320, 16, 48, 768, 174762)])
+@pytest.mark.parametrize('shape', [(2, 256, 32, 24, 768, 65536), (2, 256, 64, 10, 640, 50264), (1, 320, 64, 16, 512, 65535)])
 def test_sense_mix_gather_table_offsets_beyond_2_gib(shape):
     """The gathering mix forms `row_index * row bytes` as an UNSIGNED 32-bit offset (sense_mix_dma.hip; bp_api.hip admits
-    tables of up to 4 GiB): tables whose rows lie on both sides of byte offset 2^31 -- Small's width with 100 000 rows
-    (2.46 GB), Mini k = 64's REAL table 50 264 x 64 x 640 (4.12 GB, 96 % of the range; what `bench.py --workload
-    mini-k64-1024` and the cached vocabulary table read), and the largest table of Small's width the entry point takes
-    (174 762 rows = 4 GiB - 24 KB).  Index pinned to row 0, the rows just below / across / above 2^31 and the last row in
+    tables of up to 4 GiB and 65 536 rows): tables whose rows lie on both sides of byte offset 2^31 -- 65 536 rows of 32
+    senses x 768 (3.2 GB), Mini k = 64's REAL table 50 264 x 64 x 640 (4.12 GB, 96 % of the range; what `bench.py --workload
+    mini-k64-1024` and the cached vocabulary table read), and the largest table the entry point takes (65 535 rows of
+    64 KB = 4 GiB - 64 KB).  Index pinned to row 0, the rows just below / across / above 2^31 and the last rows in
     both samples; the rest random over the whole table.  Bit-identical to bp_sense_mix on the materialised rows."""
     bp = _bp()
     b, s, k, dk, d, rows = shape
@@ -676,7 +676,7 @@ def test_sense_mix_gather_table_offsets_beyond_2_gib(shape):
     assert torch.equal(got, want)
     # the rows beyond 2^31 matter: zeroing them changes the result (the comparison above is not vacuous)
     upper = index >= edge
-    assert upper.float().mean().item() > 0.3
+    assert upper.float().mean().item() > 0.1
     table[edge:].zero_()
     assert not torch.equal(bp.sense_mix_gather(qk, table, index), want)
     # one row more and the offsets no longer fit: refused by the support check and by the entry point (BP_ERR_SHAPE)
@@ -742,7 +742,9 @@ def test_sense_mix_gather_refuses_what_it_does_not_take():
         bp.sense_mix_gather(qk, table[:, :3], index)
     long_qk = torch.randn(1, 4160, 2, 4, 16, device=DEV).bfloat16()
     assert not bp.sense_mix_gather_supported(long_qk, table, 4160)
-    wide_qk = torch.randn(1, 2112, 2, 4, 80, device=DEV).bfloat16()      # d_k > 64: the ring leaves room for 2048 keys
-    assert not bp.sense_mix_gather_supported(wide_qk, table, 2112)
     with pytest.raises(RuntimeError, match='bp_sense_mix_gather'):
         bp.sense_mix_gather(long_qk, table, torch.zeros(1, 4160, device=DEV, dtype=torch.int32))   # BP_ERR_SHAPE: the caller gathers
+    many_rows = torch.empty(65537, 4, 64, device=DEV).bfloat16()             # the job's row indices are u16 in LDS
+    assert not bp.sense_mix_gather_supported(qk, many_rows, 64)
+    with pytest.raises(RuntimeError, match='bp_sense_mix_gather'):
+        bp.sense_mix_gather(qk, many_rows, index)
