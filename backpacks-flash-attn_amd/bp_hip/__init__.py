@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('BP_HIP_LIB') or os.path.join(_HERE, 'libbackpack_hip.so')  # env: A/B builds only
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lib = None
 

@@ -58,6 +58,14 @@ __device__ unsigned long long g_bwd_prof[2][8192][2][8];   // [kernel: 0 dq, 1 d
 
 namespace {
 
+// Development builds only (-DBP_BWD_WHATIF=<bits>, scripts/probes/flash_bwd_whatif): timing builds that DELETE one kind
+// of work (results are garbage on purpose).  1 no v_exp_f32, 2 no S / dP products, 4 no dV / dK / dQ products, 8 no
+// s_barrier (racy), 16 no epilogue stores, 32 no softmax VALU at all.  0 in the shipped library: every test below folds away.
+#ifndef BP_BWD_WHATIF
+#define BP_BWD_WHATIF 0
+#endif
+constexpr int kWhatIf = BP_BWD_WHATIF;
+
 // ring depth of the streamed tiles: tile t + NSTAGE - 1 is requested at the start of step t (three slots measured
 // against two on one box, r03_j: 0.631 vs 0.616 ms at B = 64 -- the tile latency is not what the waves wait for)
 #ifndef BP_BWD_NSTAGE
@@ -361,6 +369,7 @@ BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32
         }
 #pragma unroll
         for (int s = 0; s < KD; ++s) {
+            if (kWhatIf & 2) break;
             const u32x4 a = lds_read_16B(st, G::Q_OFF + r_off[s] + qb * 32 * C::ROW);
             s_ = E::mfma(a, kf[s], s_);
             const u32x4 b = lds_read_16B(st, G::DO_OFF + r_off[s] + qb * 32 * C::ROW);
@@ -384,7 +393,7 @@ BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 4 * g + i;
-                const float pv = fast_exp2(s_[r] * c2);
+                const float pv = (kWhatIf & 1) ? s_[r] * c2 : fast_exp2(s_[r] * c2);
                 if (DROP) {
                     const float z = ((keep >> r) & 1u) ? p.drop_scale : 0.f;
                     pe[i] = pv * z;
@@ -407,9 +416,17 @@ BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32
             dsf[g >> 1][(g & 1) * 2 + 0] = E::pack2(de[0], de[1]);
             dsf[g >> 1][(g & 1) * 2 + 1] = E::pack2(de[2], de[3]);
         }
+        if (kWhatIf & 32) {   // no softmax VALU: the raw accumulator bits stand in for the packed operands
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { pf[ks][i] = as_u32(s_[ks * 8 + i]); dsf[ks][i] = as_u32(dp[ks * 8 + i]); }
+        }
+        if (kWhatIf & 4) asm volatile("" ::"v"(pf[0]), "v"(pf[1]), "v"(dsf[0]), "v"(dsf[1]));
         // ---- dV^T += dO^T P ; dK^T += Q^T dS   (contraction over the 32 queries) -------------------
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            if (kWhatIf & 4) break;
             const int rows = (qb * 32 + ks * 16) * C::ROW;
 #pragma unroll
             for (int n = 0; n < NV; ++n) {
@@ -430,7 +447,7 @@ BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32
         const int ahead = min(nqt - 1 - qt, C::NSTAGE - 2);   // tiles requested after tile qt
         if (stats_wave) ring_wait<2 * C::DMA + 1>(ahead);
         else ring_wait<2 * C::DMA>(ahead);
-        __builtin_amdgcn_s_barrier();
+        if (!(kWhatIf & 8)) __builtin_amdgcn_s_barrier();
         if (qt + C::NSTAGE - 1 < nqt) issue(qt + C::NSTAGE - 1);
         return smem + ((qt - qt_begin) % C::NSTAGE) * G::STAGE;
     };
@@ -491,6 +508,7 @@ BP_DEV void flash_bwd_dkdv_tile(const FlashBwdParams p, char *smem, const uint32
     const int d_lim = my_key < seq_k ? p.d : 0;   // lanes past the sequence exchange, but store nothing
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
+        if (kWhatIf & 16) { asm volatile("" ::"v"(dk[n]), "v"(dv[n])); continue; }
         store_block16<E, (KD <= 4)>(dkg, dk[n], p.scale, n, hh, d_lim);
         store_block16<E, (KD <= 4)>(dvg, dv[n], 1.f, n, hh, d_lim);
     }
@@ -643,6 +661,7 @@ BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t
         for (int r = 0; r < 16; ++r) st_[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < KD; ++s) {
+            if (kWhatIf & 2) break;
             const u32x4 a = lds_read_16B(st, K_OFF + r_off[s] + kk * 32 * C::ROW);
             st_ = E::mfma(a, qf[s], st_);
             const u32x4 b = lds_read_16B(st, V_OFF + r_off[s] + kk * 32 * C::ROW);
@@ -664,7 +683,7 @@ BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 4 * g + i;
-                const float pv = fast_exp2(fmaf(st_[r], c2, lneg2));
+                const float pv = (kWhatIf & 1) ? fmaf(st_[r], c2, lneg2) : fast_exp2(fmaf(st_[r], c2, lneg2));
                 if (DROP) {
                     const float z = ((keep >> r) & 1u) ? p.drop_scale : 0.f;
                     de[i] = pv * fmaf(dpt[r], z, dneg);
@@ -676,9 +695,17 @@ BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t
             dsf[g >> 1][(g & 1) * 2 + 0] = E::pack2(de[0], de[1]);
             dsf[g >> 1][(g & 1) * 2 + 1] = E::pack2(de[2], de[3]);
         }
+        if (kWhatIf & 32) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dsf[ks][i] = as_u32(st_[ks * 8 + i]) ^ as_u32(dpt[ks * 8 + i]);
+        }
+        if (kWhatIf & 4) asm volatile("" ::"v"(dsf[0]), "v"(dsf[1]));
         // dQ^T += K^T dS^T  (contraction over the 32 keys)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            if (kWhatIf & 4) break;
             const int rows = (kk * 32 + ks * 16) * C::ROW;
 #pragma unroll
             for (int n = 0; n < NV; ++n) {
@@ -691,7 +718,7 @@ BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t
 
     auto step_begin = [&](int kb) -> const char * {
         ring_wait<2 * C::DMA>(min(nkb - 1 - kb, C::NSTAGE - 2));
-        __builtin_amdgcn_s_barrier();
+        if (!(kWhatIf & 8)) __builtin_amdgcn_s_barrier();
         if (kb + C::NSTAGE - 1 < nkb) issue(kb + C::NSTAGE - 1);
         return smem + (kb % C::NSTAGE) * STAGE;
     };
@@ -759,7 +786,10 @@ BP_DEV void flash_bwd_dq_tile(const FlashBwdParams p, char *smem, const uint32_t
     uint16_t *dqg = reinterpret_cast<uint16_t *>(p.dq) + (si.q_row0 + q_row) * p.dq_rs + (int64_t)head * p.dq_hs;
     const int d_lim = my_q < seq_q ? p.d : 0;
 #pragma unroll
-    for (int n = 0; n < NV; ++n) store_block16<E, (KD <= 4)>(dqg, dq[n], p.scale, n, hh, d_lim);
+    for (int n = 0; n < NV; ++n) {
+        if (kWhatIf & 16) { asm volatile("" ::"v"(dq[n])); continue; }
+        store_block16<E, (KD <= 4)>(dqg, dq[n], p.scale, n, hh, d_lim);
+    }
     BWD_STAMP(0, pass, 7);
 }
 

@@ -235,8 +235,9 @@ class BackpackModel(GPTPreTrainedModel):
         self.dedup_content = bool(getattr(config, 'dedup_content', True))
         self.sense_table_mode = getattr(config, 'sense_table', 'cached')      # 'cached' | 'batch' | 'off', see below
         assert self.sense_table_mode in ('cached', 'batch', 'off')
-        # 'batch' mode pays from about this many positions up (measured, profiles/r05_*_content_modes.jsonl)
-        self.dedup_min_positions = int(getattr(config, 'dedup_min_positions', 2 * config.vocab_size))
+        # 'batch' mode pays from about 0.65 x vocab positions up with uniformly random ids (Small, S = 1024: equal at 32 k
+        # positions, -6 % at 49 k, -12 % at 100 k; profiles/r05_a_content_modes_small.jsonl); text repeats tokens and pays earlier
+        self.dedup_min_positions = int(getattr(config, 'dedup_min_positions', config.vocab_size))
         self._sense_table = None
         self.gpt2_model = GPTModel(config, **factory_kwargs)
         self.content_model = BackpackContentModule(config, self.num_content_vectors,
@@ -258,7 +259,7 @@ class BackpackModel(GPTPreTrainedModel):
     #   'cached' (default)  the WHOLE vocabulary, built once per weight version (`sense_table()`); index = the ids.
     #                       Static shapes, no host sync: every batch size, graph capture, generate(cg=True).
     #   'batch'             the distinct ids of THIS batch (torch.unique, a host sync), rebuilt every forward; taken from
-    #                       `dedup_min_positions` positions up (below that the per-position order is as fast).
+    #                       `dedup_min_positions` positions up (default: one per vocabulary entry; below, per position is as fast).
     #   'off'               every position through the content network (the reference's order; also `dedup_content=False`).
     # Mathematically identical to the per-position order; bits can differ where the BLAS GEMMs round a row differently
     # when the row count changes.  Training always runs per position (dropout inside the content network, autograd).

@@ -193,7 +193,7 @@ def pick_batch(model, make_ids, candidates, seq, device, logits, steps=3, hbm_li
             # (the footprint is taken from the first candidate large enough for the deduplicated content network --
             # smaller ones also hold the per-position content tensor, 25 MB per sample at Small)
             vocab = model.lm_head.weight.shape[0]
-            if per_sample_other is None and (b * seq >= 2 * vocab or b == candidates[-1]):
+            if per_sample_other is None and (b * seq >= vocab or b == candidates[-1]):
                 per_sample_other = max(peak - fixed - logits.bytes_per_sample() * b, 0) / b
                 fit = [c for c in candidates
                        if fixed + (per_sample_other + logits.bytes_per_sample()) * c <= hbm_limit * total_mem]
@@ -417,7 +417,7 @@ def main():
     # so that all numbers come from one process on one box: a few steps, same batch, same barriers.
     hbm_peak = torch.cuda.max_memory_allocated(device)
     with torch.no_grad():
-        # which order the timed steps actually ran ('batch' falls back to per position under 2 x vocab positions)
+        # which order the timed steps actually ran ('batch' falls back to per position below vocab positions)
         if content == 'batch' and not model.transformer._dedup_applies(ids):
             content = 'position'
         if content == 'cached' and model.transformer.sense_table() is None:
@@ -434,7 +434,7 @@ def main():
             try:
                 with torch.no_grad():
                     if mode == 'batch' and not model.transformer._dedup_applies(ids[:b_o]):
-                        return dict(value=None, note='fewer than 2 x vocab positions: this order does not apply')
+                        return dict(value=None, note='fewer positions than vocabulary entries: this order does not apply')
                     model(ids[:b_o], logits_out=logits_out[:b_o])
                 torch.cuda.synchronize()   # (no collective inside the try: a rank that runs out of HBM must not leave
                 t1 = time.perf_counter()   #  the others waiting in a barrier it never reaches)

@@ -28,11 +28,12 @@
 extern "C" {
 #endif
 
-#define BP_ABI_VERSION 6   /* 2: *_dropout entry points added; 3: bias/GELU + column-sum entry points added, the
+#define BP_ABI_VERSION 7   /* 2: *_dropout entry points added; 3: bias/GELU + column-sum entry points added, the
                               persistent sense-mix launches take a caller-owned `queue_ws`; 4: bp_flash_bwd* take the
                               size of `dsum_ws` (bp_flash_bwd_ws_floats) and check it, queue_ws == NULL is refused
                               while the stream is capturing (BP_ERR_QUEUE_WS); 5: bp_dropout_add_layer_norm_scaled{,_bwd}
-                              (rowscale / colscale of the reference's dropout_add_ln) added; 6: bp_sense_mix_gather added */
+                              (rowscale / colscale of the reference's dropout_add_ln) added; 6: bp_sense_mix_gather added;
+                              7: bp_sense_mix_gather clamps row_index to the table and takes tables of at most 65 536 rows */
 
 /* element type of q/k/v/out/content tensors */
 #define BP_DTYPE_F16 0

@@ -111,7 +111,7 @@ def test_token_tables_against_the_oracle(name):
     """The two inference orders that run the content network per TOKEN, checked DIRECTLY against the oracle (round-4
     review: the deduplicated path was only compared with the HIP per-position path):
       * the cached whole-vocabulary sense table (the default in eval), B = 2: the oracle's two samples;
-      * the table of the batch's distinct tokens (torch.unique), which only exists from 2 x vocab positions up: a batch of
+      * the table of the batch's distinct tokens (torch.unique), taken from vocab positions up: a batch of
         100 samples whose first two are the oracle's.
     Small's table is 1.2 GB; Mini k = 64's 4.1 GB, i.e. byte offsets beyond 2^31 and up to 96 % of the 32-bit range."""
     run = _oracle_run(name)
@@ -127,7 +127,7 @@ def test_token_tables_against_the_oracle(name):
     big[:2] = ids
     t.sense_table_mode = 'batch'
     with torch.no_grad():
-        assert t._dedup_applies(big.to(DEV)) and not t._dedup_applies(big[:97].to(DEV))
+        assert t._dedup_applies(big.to(DEV)) and not t._dedup_applies(big[:48].to(DEV))      # vocab positions up
     hid = _hidden(run, big, 'batch')[:2]
     _assert_model_parity(run, hid, f'{name} table of the distinct tokens of a batch of 100')
 

@@ -54,7 +54,7 @@ def test_nano_model_hip_vs_golden(fused):
 def test_content_dedup_matches_the_per_position_content_network():
     """Inference forward with the content network run once per distinct token (default) against the same model with
     `dedup_content` off (the reference's order: every position): same hidden states and logits to bf16 GEMM noise, the
-    switch conditions honoured (taken for >= 2 x vocab positions under no_grad in eval; not in training, not with
+    switch conditions honoured (taken for >= vocab positions under no_grad in eval; not in training, not with
     autograd, not for small inputs)."""
     g, sd, model = _nano(fused=True)
     t = model.transformer
@@ -64,7 +64,7 @@ def test_content_dedup_matches_the_per_position_content_network():
     orig = t._table_of_unique_tokens
     t._table_of_unique_tokens = lambda x: (calls.append(x.shape), orig(x))[1]
     with torch.no_grad():
-        assert t._dedup_applies(ids) and not t._dedup_applies(ids[:2])        # 256 >= 192 positions; 64 < 192
+        assert t._dedup_applies(ids) and not t._dedup_applies(ids[:2])        # 256 >= 96 (= vocab) positions; 64 < 96
         hid = t(ids)
         logits = model(ids).logits
         assert len(calls) == 2
@@ -326,9 +326,10 @@ def test_bench_script_contract():
     assert {k['kernel'] for k in d['kernels']} >= {'flash_fwd_kernel', 'sense_mix_kernel', 'add_layer_norm_kernel'}
 
 
-def test_bench_reports_both_content_orders():
-    """At a batch where inference takes the deduplicated content path (1024 x 128 positions >= 2 x vocab), the bench line
-    says so and carries the per-position order timed in the same process; --no-content-dedup makes that the headline."""
+def test_bench_reports_all_three_content_orders():
+    """At a batch with more positions than vocabulary entries (1024 x 128) the bench line's `value` is the step with the
+    table of the batch's distinct tokens rebuilt per step, and the same process times the reference's per-position order
+    and the cached whole-vocabulary table next to it; --content picks which one is the headline."""
     import json
     import os
     import subprocess
@@ -340,12 +341,19 @@ def test_bench_reports_both_content_orders():
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])
     assert d['config']['content_network'].startswith('once per distinct token')
-    pp = d['content_per_position']
-    assert pp['value'] > 0 and pp['steps'] == 3 and pp['batch_per_gpu'] == 1024 and pp['unit'] == 'tokens/s'
+    for key in ('content_per_position', 'content_cached_table'):
+        other = d[key]
+        assert other['value'] > 0 and other['steps'] == 3 and other['batch_per_gpu'] == 1024 and other['unit'] == 'tokens/s'
+    assert 'content_per_batch_table' not in d
     out = subprocess.run(base + ['--no-content-dedup'], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     d2 = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])
-    assert d2['config']['content_network'] == 'once per position' and 'content_per_position' not in d2
+    assert d2['config']['content_network'].startswith('once per position') and 'content_per_position' not in d2
+    assert d2['content_cached_table']['value'] > 0 and d2['content_per_batch_table']['value'] > 0
+    out = subprocess.run(base + ['--content', 'cached', '--graph'], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d3 = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])
+    assert d3['config']['content_network'].startswith('whole-vocabulary') and d3['launch'] == 'hip-graph replay'
 
 
 def test_greedy_generation_on_the_hip_path():

@@ -420,7 +420,7 @@ def test_content_of_unique_tokens_equals_the_per_position_content():
     rows (BackpackModel._content_of_unique_tokens): the sense vectors are a function of the token alone (reference
     backpack.py:251-276: no positions, Identity mixer).  On the CPU, in fp32, the gathered tensor equals the
     per-position one; the switch itself is taken only where it is exact and pays (GPU, eval, no autograd, no capture,
-    >= 2 x vocabulary positions)."""
+    >= vocabulary-size positions)."""
     torch.manual_seed(0)
     model = BackpackLMHeadModel(nano_config()).eval()
     t = model.transformer
