@@ -79,19 +79,11 @@ BP_DEV void dma16_s_nt(const uint16_t *uniform_base, uint32_t lane_byte_off, uin
         : "memory", "m0");
 }
 
-// Plain global loads the compiler does not wait for: the caller owns the completion (an `s_waitcnt vmcnt(N)` that
-// accounts for everything issued after them, then a pin on the result, before the first use).  Lets per-sense
-// operands be requested a ring step ahead without the compiler's own `vmcnt(0)` draining the DMA ring.
-BP_DEV u32x4 ld_global_16B_async(const uint16_t *p) {
-    u32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-BP_DEV float ld_global_f32_async(const float *p) {
-    float v;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
+// (Rounds 3-4 had `ld_global_16B_async` here: plain global loads in inline asm whose completion the caller owned, for
+// operands requested a ring step ahead.  Removed in round 5: the compiler may copy an asm OUTPUT register at any time -- a
+// phi copy at a control-flow join, a live-range split -- and such a copy read the destination before the data had landed
+// (sense_mix_dma.hip's next-sense operands: NaN outputs).  Operands that must travel across ring steps go through LDS
+// with the DMA forms above; loads whose result is used right away are plain C++ loads.)
 
 BP_DEV uint32_t lds_base_addr(char *smem) { return (uint32_t)(uintptr_t)(lmem_v *)smem; }
 
