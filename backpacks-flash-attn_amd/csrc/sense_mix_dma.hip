@@ -431,7 +431,7 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
                     u32x4 a_next = a;
                     if (n + 1 < C::NB) a_next = c_operand(rows, n + 1);
                     asm volatile("" : "+v"(a));
-                    acc[n] = E::mfma(a, pf0[0], acc[n]);
+                    if (FULL || n < nb_live) acc[n] = E::mfma(a, pf0[0], acc[n]);   // (partial last column chunk: d = 640, 384, ...)
                     asm volatile("" : "+v"(acc[n]));
                     float x0 = st1[2 * n], x1 = st1[2 * n + 1];
                     asm volatile("" : "+v"(x0), "+v"(x1));
