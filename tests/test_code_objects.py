@@ -28,6 +28,9 @@ HOT = [
     ('sense_mix_dma.o', 'sense_mix_dma_kernel<BF16, 1, false, false, false>', 2),
     # the same with the content rows gathered from the per-token table (inference, bp_sense_mix_gather)
     ('sense_mix_dma.o', 'sense_mix_dma_kernel<BF16, 3, true, false, true>', 2),
+    ('sense_mix_dma.o', 'sense_mix_dma_kernel<F16, 3, true, false, true>', 2),       # config 5 (S = 4096 fp16)
+    ('sense_mix_dma.o', 'sense_mix_dma_kernel<BF16, 1, false, false, true>', 2),     # config 4 (Mini k = 64: 640 columns)
+    ('sense_mix_dma.o', 'sense_mix_dma_kernel<BF16, 2, false, false, true>', 2),     # config 1 (Micro: d_k = 24, 384 columns)
     # training step (config 3): attention backward at d_h = 64 with and without dropout, sense-mix dC
     # dK/dV at three waves per SIMD (168 registers): ONE 64-bit value still goes to scratch, stored in front of the
     # clean-tile loop and reloaded behind it, once per pass -- no tile loop of the kernel touches scratch (round 3: 12
