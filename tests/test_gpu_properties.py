@@ -1,0 +1,253 @@
+"""-m gpu: size-independent properties of the hot path at BASELINE.json's real shapes.
+
+The oracle finishes in seconds only at two samples per configuration (tests/test_gpu_configs.py); at the sizes the
+bench runs, the path is checked through properties that need no oracle and hold BIT FOR BIT, because they are statements
+about indexing, masks and work distribution, not about rounding:
+  * causality -- nothing at or before position t may depend on what lies behind t (the reference's causal mask,
+    csrc/flash_attn/src/fmha/mask.h:57-70; training/src/models/backpack.py:116-122): the rows behind t are replaced by
+    other values, so a key that leaks through a mask or an index that runs past t changes bits.  One extra cut replaces
+    them by much LARGER values: there the softmax kernels may take their overflow-retry branch, which is decided per
+    WAVE (32 queries, csrc/flash_fwd_dma.hip `tile`), so a row that shares its wave with replaced rows may come out
+    through the textbook branch instead of the fixed-reference one -- a different rounding of the same value, checked
+    against the kernels' own tolerance instead of bit for bit;
+  * sample independence -- permuting the samples of a batch permutes the result (every kernel here maps samples to
+    workgroups differently: XCD-local groups in the attention kernels, per-XCD ticket queues in the sense mix);
+  * determinism -- the same call twice gives the same bits (no atomics on the data path).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _bp():
+    import bp_hip
+    return bp_hip
+
+
+def _flash(qkv, scale):
+    """qkv (B,S,3,H,D) -> out (B,S,H,D), lse (B,H,S); causal, fixed length (the trunk's call)."""
+    bp = _bp()
+    b, s, _, h, d = qkv.shape
+    flat = qkv.reshape(b * s, 3, h, d)
+    out = torch.empty_like(flat[:, 0])
+    cu = torch.arange(0, (b + 1) * s, s, dtype=torch.int32, device=qkv.device)
+    lse = bp.flash_fwd(flat[:, 0], flat[:, 1], flat[:, 2], out, cu, cu, s, s, scale, True)
+    return out.reshape(b, s, h, d), lse[:, :, :s].clone()
+
+
+# (name, batch, seq, heads, head dim, dtype, trunk layer whose scale is used): BASELINE configs 2, 4 and 5
+FLASH_SHAPES = [('small-1024', 24, 1024, 12, 64, torch.bfloat16, 0),
+                ('small-1024-layer11', 8, 1024, 12, 64, torch.bfloat16, 11),
+                ('mini-k64-1024', 16, 1024, 8, 80, torch.bfloat16, 3),
+                ('small-4096-fp16', 4, 4096, 12, 64, torch.float16, 5)]
+
+
+@pytest.mark.parametrize('name,b,s,h,d,dtype,layer', FLASH_SHAPES, ids=[x[0] for x in FLASH_SHAPES])
+def test_flash_fwd_causality_sample_independence_determinism(name, b, s, h, d, dtype, layer):
+    g = torch.Generator(device=DEV).manual_seed(11)
+    qkv = torch.randn(b, s, 3, h, d, device=DEV, generator=g).to(dtype)
+    scale = d ** -0.5 / (layer + 1)
+    out, lse = _flash(qkv, scale)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(lse).all()
+    again, lse_again = _flash(qkv, scale)
+    assert torch.equal(out, again) and torch.equal(lse, lse_again), 'two identical launches differ'
+    # causality at cuts inside a 32-key block, on a 64-key tile border and on a 128-query tile border
+    for t0 in (s // 2 + 37, s // 2 + 64, s - 128, 1):
+        other = qkv.clone()
+        other[:, t0:] = torch.randn(b, s - t0, 3, h, d, device=DEV, generator=g).to(dtype)
+        got, lse_got = _flash(other, scale)
+        assert torch.equal(got[:, :t0], out[:, :t0]), f'{name}: rows before {t0} changed with the rows behind it'
+        assert torch.equal(lse_got[:, :, :t0], lse[:, :, :t0]), f'{name}: log-sum-exp before {t0} changed'
+        assert not torch.equal(got[:, t0:], out[:, t0:])
+    t0 = s // 2 + 37                     # the loud cut (see the module docstring)
+    other = qkv.clone()
+    other[:, t0:] = (6.0 * torch.randn(b, s - t0, 3, h, d, device=DEV, generator=g)).to(dtype)
+    got, lse_got = _flash(other, scale)
+    assert (got[:, :t0].float() - out[:, :t0].float()).abs().max().item() <= 2.0 ** -6 * out.float().abs().max().item()
+    assert (lse_got[:, :, :t0] - lse[:, :, :t0]).abs().max().item() < 1e-3
+    assert torch.isfinite(got.float()).all() and torch.isfinite(lse_got).all()
+    perm = torch.randperm(b, device=DEV, generator=g)
+    got, lse_got = _flash(qkv[perm].contiguous(), scale)
+    assert torch.equal(got, out[perm]) and torch.equal(lse_got, lse[perm]), f'{name}: samples are not independent'
+
+
+# (name, batch, seq, senses, d_k, d, dtype): the sense kernels of BASELINE configs 2, 4 and 5
+MIX_SHAPES = [('small-1024', 12, 1024, 16, 48, 768, torch.bfloat16),
+              ('mini-k64-1024', 4, 1024, 64, 10, 640, torch.bfloat16),
+              ('small-4096-fp16', 2, 4096, 16, 48, 768, torch.float16)]
+
+
+@pytest.mark.parametrize('name,b,s,k,dk,d,dtype', MIX_SHAPES, ids=[x[0] for x in MIX_SHAPES])
+def test_sense_lse_and_mix_causality_sample_independence_determinism(name, b, s, k, dk, d, dtype):
+    bp = _bp()
+    g = torch.Generator(device=DEV).manual_seed(12)
+    qk = (1.5 * torch.randn(b, s, 2, k, dk, device=DEV, generator=g)).to(dtype)
+    c = torch.randn(b, s, k, d, device=DEV, generator=g).to(dtype)
+    lse = bp.sense_lse(qk)[:, :, :s].clone()
+    out = bp.sense_mix(qk, c)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(lse).all()
+    assert torch.equal(bp.sense_mix(qk, c), out) and torch.equal(bp.sense_lse(qk)[:, :, :s], lse)
+    # cuts inside a 32-key block, on a 64-key tile border and on a 256-query tile border
+    for t0 in (s // 2 + 37, s // 2 + 64, s - 256, 1):
+        qk2, c2 = qk.clone(), c.clone()
+        qk2[:, t0:] = (1.5 * torch.randn(b, s - t0, 2, k, dk, device=DEV, generator=g)).to(dtype)
+        c2[:, t0:] = (3.0 * torch.randn(b, s - t0, k, d, device=DEV, generator=g)).to(dtype)
+        assert torch.equal(bp.sense_lse(qk2)[:, :, :t0], lse[:, :, :t0]), f'{name}: sense LSE before {t0} changed'
+        got = bp.sense_mix(qk2, c2)
+        assert torch.equal(got[:, :t0], out[:, :t0]), f'{name}: mixed rows before {t0} changed with the rows behind it'
+        assert not torch.equal(got[:, t0:], out[:, t0:])
+    # the loud cut (module docstring): the LSE pre-pass may answer through its retry branch; with the SAME log-sum-exp
+    # handed in, the mix itself has no such branch and stays bit-exact
+    t0 = s // 2 + 37
+    qk2, c2 = qk.clone(), c.clone()
+    qk2[:, t0:] = (6.0 * torch.randn(b, s - t0, 2, k, dk, device=DEV, generator=g)).to(dtype)
+    c2[:, t0:] = (3.0 * torch.randn(b, s - t0, k, d, device=DEV, generator=g)).to(dtype)
+    lse2 = bp.sense_lse(qk2)
+    assert torch.isfinite(lse2[:, :, :s]).all()
+    assert (lse2[:, :, :t0] - lse[:, :, :t0]).abs().max().item() < 1e-3
+    lse_mixed = lse2.clone()
+    lse_mixed[:, :, :t0] = lse[:, :, :t0]
+    got = bp.sense_mix(qk2, c2, lse=lse_mixed)
+    assert torch.isfinite(got.float()).all()
+    assert torch.equal(got[:, :t0], out[:, :t0]), f'{name}: mixed rows before {t0} changed with the (loud) rows behind it'
+    perm = torch.randperm(b, device=DEV, generator=g)
+    assert torch.equal(bp.sense_mix(qk[perm].contiguous(), c[perm].contiguous()), out[perm]), \
+        f'{name}: samples are not independent'
+    assert torch.equal(bp.sense_lse(qk[perm].contiguous())[:, :, :s], lse[perm])
+
+
+@pytest.mark.parametrize('name,b,s,k,dk,d,dtype', MIX_SHAPES, ids=[x[0] for x in MIX_SHAPES])
+def test_sense_mix_gather_causality_and_sample_independence(name, b, s, k, dk, d, dtype):
+    """The table form (content[b, s] = table[index[b, s]]): the same properties in terms of the INDEX, and equality with the
+    dense form on the rows it names."""
+    bp = _bp()
+    g = torch.Generator(device=DEV).manual_seed(13)
+    rows = 3001
+    qk = (1.5 * torch.randn(b, s, 2, k, dk, device=DEV, generator=g)).to(dtype)
+    table = torch.randn(rows, k, d, device=DEV, generator=g).to(dtype)
+    idx = torch.randint(0, rows, (b, s), device=DEV, generator=g, dtype=torch.int32)
+    assert bp.sense_mix_gather_supported(qk, table, s)
+    out = bp.sense_mix_gather(qk, table, idx)
+    assert torch.equal(out, bp.sense_mix(qk, table[idx.long()])), f'{name}: table form differs from the dense form'
+    assert torch.equal(out, bp.sense_mix_gather(qk, table, idx))
+    for t0 in (s // 2 + 37, s - 256):
+        idx2 = idx.clone()
+        idx2[:, t0:] = torch.randint(0, rows, (b, s - t0), device=DEV, generator=g, dtype=torch.int32)
+        got = bp.sense_mix_gather(qk, table, idx2)
+        assert torch.equal(got[:, :t0], out[:, :t0]), f'{name}: rows before {t0} depend on later table indices'
+    perm = torch.randperm(b, device=DEV, generator=g)
+    assert torch.equal(bp.sense_mix_gather(qk[perm].contiguous(), table, idx[perm].contiguous()), out[perm])
+
+
+def _small_model(seq, dtype, **over):
+    from src.models.backpack import BackpackConfig, BackpackLMHeadModel
+    kw = dict(n_embd=768, n_head=12, n_layer=12, num_content_vectors=16, vocab_size=50264, n_positions=seq,
+              scale_attn_by_inverse_layer_idx=True, resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0,
+              use_flash_attn=True, fused_dropout_add_ln=True, fused_dense_gelu_dense=True, fused_bias_fc=True,
+              pad_vocab_size_multiple=8)
+    kw.update(over)
+    torch.manual_seed(0)
+    model = BackpackLMHeadModel(BackpackConfig(**kw))
+    with torch.no_grad():   # the default init gives near-uniform attention: sharpen it so that the softmax paths matter
+        model.transformer.contextualization_attn.Wqkv.weight.mul_(8.0)
+        for layer in model.transformer.gpt2_model.layers:
+            layer.mixer.Wqkv.weight.mul_(6.0)
+    return model.to(DEV, dtype).eval()
+
+
+@pytest.mark.parametrize('mode', ['off', 'cached'])
+def test_backpack_small_forward_is_causal_at_seq1024(mode):
+    """BASELINE config 2 as a whole model (ids -> final hidden states -> logits), batch 8: the hidden states and logits of
+    the positions before a cut are the same BITS whatever tokens follow -- with the content network per position (the
+    reference's order, 'off') and with the cached whole-vocabulary sense table (the inference default).  Every layer
+    between the kernels is row-wise (LayerNorm, library GEMMs of an unchanged shape), so one leaking key anywhere in the
+    24 attention launches or the sense mix shows."""
+    model = _small_model(1024, torch.bfloat16)
+    t = model.transformer
+    t.sense_table_mode = mode
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, 50257, (8, 1024), generator=g).to(DEV)
+    with torch.no_grad():
+        hid = t(ids)
+        if not torch.equal(hid, t(ids)):
+            pytest.skip('the library GEMMs of this box are not run-to-run deterministic: nothing bit-exact to compare')
+        # a cut on a 32-row border: every wave of every kernel lies entirely before or entirely behind it
+        t0 = 576
+        ids2 = ids.clone()
+        ids2[:, t0:] = torch.randint(0, 50257, (8, 1024 - t0), generator=g).to(DEV)
+        hid2 = t(ids2)
+        assert torch.equal(hid2[:, :t0], hid[:, :t0]), 'hidden states before the cut depend on the tokens behind it'
+        assert not torch.equal(hid2[:, t0:], hid[:, t0:])
+        rows = torch.arange(0, t0, 7, device=DEV)
+        assert torch.equal(model.lm_head(hid2[:, rows]), model.lm_head(hid[:, rows]))
+        # a cut inside a wave's 32 rows (544 .. 575): the rows of the waves before it are still the same bits; rows 544 .. 548
+        # share their wave with replaced rows, and the softmax kernels decide their overflow-retry branch per wave (module
+        # docstring; the sharpened weights of this model take it often) -- another rounding, twelve layers deep
+        t0 = 549
+        ids2 = ids.clone()
+        ids2[:, t0:] = torch.randint(0, 50257, (8, 1024 - t0), generator=g).to(DEV)
+        hid2 = t(ids2)
+        assert torch.equal(hid2[:, :544], hid[:, :544]), 'rows of the waves before the cut changed'
+        miss = (hid2[:, 544:t0].float() - hid[:, 544:t0].float()).abs().max().item()
+        print(f'rows 544..548 with {mode!r} content: max |difference| {miss:.3e} of max |hidden| '
+              f'{hid.float().abs().max().item():.2f}')
+        assert miss <= 0.05 * hid.float().abs().max().item()
+    assert torch.isfinite(hid.float()).all()
+
+
+def _flash_bwd(qkv, dout, scale):
+    """Forward + backward of the causal trunk attention through the C ABI: returns out, dq, dk, dv as (B,S,H,D)."""
+    bp = _bp()
+    b, s, _, h, d = qkv.shape
+    flat = qkv.reshape(b * s, 3, h, d)
+    q, k, v = flat[:, 0], flat[:, 1], flat[:, 2]
+    out = torch.empty_like(q)
+    lse = bp.flash_fwd(q, k, v, out, None, None, s, s, scale, True)
+    dq, dk, dv = (torch.empty(b * s, h, d, dtype=qkv.dtype, device=qkv.device) for _ in range(3))
+    bp.flash_bwd(dout.reshape(b * s, h, d), q, k, v, out, lse, dq, dk, dv, None, None, s, s, scale, True)
+    return tuple(x.reshape(b, s, h, d) for x in (out, dq, dk, dv))
+
+
+BWD_SHAPES = [('small-1024', 32, 1024, 12, 64, torch.bfloat16), ('mini-k64-1024', 8, 1024, 8, 80, torch.bfloat16)]
+
+
+@pytest.mark.parametrize('name,b,s,h,d,dtype', BWD_SHAPES, ids=[x[0] for x in BWD_SHAPES])
+def test_flash_bwd_causality_sample_independence_determinism(name, b, s, h, d, dtype):
+    """BASELINE config 3's attention backward at the training batch (32 samples per GPU), all bit-exact:
+      * dQ of the rows before t depends on nothing behind t (q, k, v and dO there are replaced);
+      * with dO = 0 behind t no gradient flows into the rows behind t (dQ, dK, dV there are exact zeros), and before t all
+        three gradients are those of the problem truncated at t, launched as its own (shorter, ragged) batch;
+      * the same call twice gives the same bits (two kernels, no atomics; the reference's loop kernel is deterministic
+        too, tests/test_flash_attn.py:788-793), and permuting the samples permutes the gradients."""
+    g = torch.Generator(device=DEV).manual_seed(21)
+    qkv = torch.randn(b, s, 3, h, d, device=DEV, generator=g).to(dtype)
+    dout = torch.randn(b, s, h, d, device=DEV, generator=g).to(dtype)
+    scale = d ** -0.5
+    out, dq, dk, dv = _flash_bwd(qkv, dout, scale)
+    for x in (dq, dk, dv):
+        assert torch.isfinite(x.float()).all()
+    again = _flash_bwd(qkv, dout, scale)
+    assert all(torch.equal(a, c) for a, c in zip(again, (out, dq, dk, dv))), 'two identical launches differ'
+    for t0 in (s // 2 + 37, s - 128):
+        qkv2, dout2 = qkv.clone(), dout.clone()
+        qkv2[:, t0:] = (2.0 * torch.randn(b, s - t0, 3, h, d, device=DEV, generator=g)).to(dtype)
+        dout2[:, t0:] = (2.0 * torch.randn(b, s - t0, h, d, device=DEV, generator=g)).to(dtype)
+        _, dq2, _, _ = _flash_bwd(qkv2, dout2, scale)
+        assert torch.equal(dq2[:, :t0], dq[:, :t0]), f'{name}: dQ before {t0} changed with the rows behind it'
+        # no gradient flows into the rows behind t when dO is zero there: dK / dV behind t are exact zeros, and before t
+        # they are the gradients of the problem truncated at t
+        dout0 = dout.clone()
+        dout0[:, t0:] = 0
+        _, dq0, dk0, dv0 = _flash_bwd(qkv, dout0, scale)
+        assert torch.count_nonzero(dk0[:, t0:]) == 0 and torch.count_nonzero(dv0[:, t0:]) == 0
+        assert torch.count_nonzero(dq0[:, t0:]) == 0
+        _, dq_t, dk_t, dv_t = _flash_bwd(qkv[:, :t0].contiguous(), dout[:, :t0].contiguous(), scale)
+        assert torch.equal(dq0[:, :t0], dq_t)
+        # (the queries behind t add exact zeros to dK / dV in the full problem; the truncated one masks them in its last,
+        # partial tile: the same bits either way)
+        assert torch.equal(dk0[:, :t0], dk_t) and torch.equal(dv0[:, :t0], dv_t)
+    perm = torch.randperm(b, device=DEV, generator=g)
+    got = _flash_bwd(qkv[perm].contiguous(), dout[perm].contiguous(), scale)
+    assert all(torch.equal(a, c[perm]) for a, c in zip(got, (out, dq, dk, dv))), f'{name}: samples are not independent'
