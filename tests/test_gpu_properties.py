@@ -251,3 +251,50 @@ def test_flash_bwd_causality_sample_independence_determinism(name, b, s, h, d, d
     perm = torch.randperm(b, device=DEV, generator=g)
     got = _flash_bwd(qkv[perm].contiguous(), dout[perm].contiguous(), scale)
     assert all(torch.equal(a, c[perm]) for a, c in zip(got, (out, dq, dk, dv))), f'{name}: samples are not independent'
+
+
+def _mix_grads(qk, c, dout):
+    """dqk, dcontent of the fused sense contraction (bp_hip.SenseMixFn: LSE pre-pass, mix, dC kernel, slab GEMMs + dq / dk)."""
+    bp = _bp()
+    qk = qk.detach().clone().requires_grad_(True)
+    c = c.detach().clone().requires_grad_(True)
+    out = bp.sense_mix_autograd(qk, c)
+    out.backward(dout)
+    return out.detach(), qk.grad, c.grad
+
+
+MIX_BWD_SHAPES = [('small-1024', 8, 1024, 16, 48, 768), ('mini-k16-1024', 8, 1024, 16, 40, 640)]
+
+
+@pytest.mark.parametrize('name,b,s,k,dk,d', MIX_BWD_SHAPES, ids=[x[0] for x in MIX_BWD_SHAPES])
+def test_sense_mix_backward_causality_sample_independence_determinism(name, b, s, k, dk, d):
+    """The backward of the sense contraction at config 3's shape (and Mini's widths), bit-exact:
+      * two identical calls agree; permuting the samples permutes dqk and dC;
+      * with dout = 0 behind a cut no gradient reaches the rows behind it (dq, dk, dC there are exact zeros);
+      * before the cut dC (one kernel) is the dC of the problem truncated there, wherever the cut lies; dq / dk go through
+        slab GEMMs of the BLAS library (128 queries per slab), so they are compared at a cut on a slab border, where the
+        truncated problem issues the same GEMM shapes."""
+    g = torch.Generator(device=DEV).manual_seed(31)
+    dtype = torch.bfloat16
+    qk = (1.5 * torch.randn(b, s, 2, k, dk, device=DEV, generator=g)).to(dtype)
+    c = torch.randn(b, s, k, d, device=DEV, generator=g).to(dtype)
+    dout = torch.randn(b, s, d, device=DEV, generator=g).to(dtype)
+    out, dqk, dc = _mix_grads(qk, c, dout)
+    assert torch.isfinite(dqk.float()).all() and torch.isfinite(dc.float()).all()
+    again = _mix_grads(qk, c, dout)
+    assert all(torch.equal(x, y) for x, y in zip(again, (out, dqk, dc))), 'two identical calls differ'
+    perm = torch.randperm(b, device=DEV, generator=g)
+    got = _mix_grads(qk[perm].contiguous(), c[perm].contiguous(), dout[perm].contiguous())
+    assert all(torch.equal(x, y[perm]) for x, y in zip(got, (out, dqk, dc))), f'{name}: samples are not independent'
+    for t0 in (s // 2 + 128, s // 2 + 37):
+        dout0 = dout.clone()
+        dout0[:, t0:] = 0
+        _, dqk0, dc0 = _mix_grads(qk, c, dout0)
+        assert torch.count_nonzero(dc0[:, t0:]) == 0 and torch.count_nonzero(dqk0[:, t0:]) == 0
+        _, dqk_t, dc_t = _mix_grads(qk[:, :t0].contiguous(), c[:, :t0].contiguous(), dout[:, :t0].contiguous())
+        assert torch.equal(dc0[:, :t0], dc_t), f'{name}: dC before {t0} is not the truncated problem\'s'
+        if t0 % 128 == 0:
+            assert torch.equal(dqk0[:, :t0], dqk_t), f'{name}: dq / dk before {t0} are not the truncated problem\'s'
+        else:
+            miss = (dqk0[:, :t0].float() - dqk_t.float()).abs().max().item()
+            assert miss <= 2.0 ** -6 * dqk_t.float().abs().max().item(), (name, t0, miss)
