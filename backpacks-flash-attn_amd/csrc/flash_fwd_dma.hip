@@ -12,9 +12,10 @@
 //     p >= 0 the tile's row sum bounds every p from above: ONE wave-wide compare of the 32 partial sums
 //     against 2^14 (fp16) / 2^30 (bf16) validates the tile after the fact.  If it fails (a score jumped far
 //     above everything the row has seen), nothing has been accumulated yet; the EXACT body recomputes the
-//     tile from LDS with the textbook online-softmax step (true maximum, rescale of O and l).  The exact
-//     body also serves every tile that needs masking (sequence end, causal diagonal) and the first tile
-//     of a row, which sets m.  The reference keeps the exact form for every tile
+//     tile from LDS with the textbook online-softmax step (true maximum, rescale of O and l) -- for the rows
+//     whose own sums failed; the other rows of the wave keep their reference point through the repeat, so a
+//     row's bits never depend on its wave-mates (online_max_step).  The exact body also serves every tile that
+//     needs masking (sequence end, causal diagonal) and the first tile of a row, which sets m.  The reference keeps the exact form for every tile
 //     (csrc/flash_attn/src/fmha/softmax.h:238-251, fmha_fprop_kernel_1xN.h:429-444); results agree to
 //     rounding because softmax is invariant to the reference point.
 //   * without dropout, P is rounded to 16 bit right behind the exponential and the row sum runs over the rounded
@@ -362,7 +363,12 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
 
     // Textbook online-softmax bookkeeping of one tile, on raw scores (in place): mask what my row may not see,
     // take the true tile maximum, move the row's reference maximum and rescale O and l accordingly.
-    auto online_max_step = [&](int kb, f32x16 (&st)[2]) {
+    // `moves` (per lane): this row takes the tile's maximum into its reference point.  True for every row of a tile that
+    // is exact by POSITION (first tile, masked tile); in a RETRY only for the rows whose own sums failed the validation --
+    // the others keep their reference (alpha = 1 exactly, the same exponent offsets), i.e. they come out with the bits the
+    // steady-state body would have given them: whether a wave repeats a tile depends on all 32 rows, the result of a row
+    // only on that row (tests/test_gpu_properties.py: what precedes a cut never depends on what follows it).
+    auto online_max_step = [&](int kb, f32x16 (&st)[2], bool moves) {
         // register r of half kk holds key base + kk*32 + (r&3) + 8*(r>>2) + 4*hh: dead iff that exceeds the last
         // visible key of my row -> ONE per-lane limit against compile-time constants
         int last = seq_k - 1;
@@ -385,11 +391,13 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
             mxd = fmaxf(mxd, st[1][8 + r]);
         }
         const float mt = xhalf_max(fmaxf(fmaxf(mxa, mxb), fmaxf(mxc, mxd)));
-        const float m_new = fmaxf(mt, m_run);
+        const float m_new = moves ? fmaxf(mt, m_run) : m_run;
         // alpha = 1 exactly for a row whose maximum did not move; exp2(-inf - x) = 0 for a fresh row, whose (zero) O
         // and l are "rescaled" harmlessly
-        const float mc_new = (m_new == -INFINITY) ? 0.f : m_new * c2;
-        const float alpha = fast_exp2(m_run * c2 - mc_new);
+        const float mc_new = !moves ? mc : (m_new == -INFINITY) ? 0.f : m_new * c2;
+        // (a row that keeps its reference: 1 by construction, not by the exponent's arithmetic -- contracted into an fma,
+        // m_run * c2 - mc_new is the rounding error of the product, not 0)
+        const float alpha = moves ? fast_exp2(m_run * c2 - mc_new) : 1.f;
         l_run *= alpha;
         if (HAS_V) {
 #pragma unroll
@@ -408,6 +416,7 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
     auto tile = [&](int kb, const char *kbuf, const char *vbuf, bool exact) {
         f32x16 st[2];
         float rs;
+        bool moves = true;
         const bool fast_entry = !exact;
         FWD_TICK(t0);
 #ifdef BP_FWD_PROFILE
@@ -431,9 +440,11 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
             asm volatile("" : "+v"(st[0]), "+v"(st[1]));
             t_s = __builtin_readcyclecounter();
 #endif
-            if (__builtin_expect(exact, 0)) online_max_step(kb, st);
+            if (__builtin_expect(exact, 0)) online_max_step(kb, st, moves);
             rs = PACKED_SUM ? exponentiate_packed(st) : exponentiate(st);
             if (__builtin_expect(exact || __all(rs <= kLimit), 1)) break;   // inf and NaN fail the test too
+            // a row's keys are summed by two lanes (l and l ^ 32): the row moves if either share failed
+            moves = xhalf_max(rs <= kLimit ? 0.f : 1.f) != 0.f;
             exact = true;
         }
 #ifdef BP_FWD_PROFILE

@@ -5,11 +5,10 @@ bench runs, the path is checked through properties that need no oracle and hold 
 about indexing, masks and work distribution, not about rounding:
   * causality -- nothing at or before position t may depend on what lies behind t (the reference's causal mask,
     csrc/flash_attn/src/fmha/mask.h:57-70; training/src/models/backpack.py:116-122): the rows behind t are replaced by
-    other values, so a key that leaks through a mask or an index that runs past t changes bits.  One extra cut replaces
-    them by much LARGER values: there the softmax kernels may take their overflow-retry branch, which is decided per
-    WAVE (32 queries, csrc/flash_fwd_dma.hip `tile`), so a row that shares its wave with replaced rows may come out
-    through the textbook branch instead of the fixed-reference one -- a different rounding of the same value, checked
-    against the kernels' own tolerance instead of bit for bit;
+    other values -- of the same scale, and 6x LOUDER ones, which drive the softmax kernels into their overflow-retry
+    branch: whether a wave (32 queries) repeats a tile is decided on all its rows, but a row whose own sums passed keeps
+    its reference point in the repeat (csrc/flash_fwd_dma.hip `online_max_step`), so its bits do not depend on its
+    wave-mates -- a key that leaks through a mask or an index that runs past t changes bits, nothing else may;
   * sample independence -- permuting the samples of a batch permutes the result (every kernel here maps samples to
     workgroups differently: XCD-local groups in the attention kernels, per-XCD ticket queues in the sense mix);
   * determinism -- the same call twice gives the same bits (no atomics on the data path).
@@ -61,13 +60,13 @@ def test_flash_fwd_causality_sample_independence_determinism(name, b, s, h, d, d
         assert torch.equal(got[:, :t0], out[:, :t0]), f'{name}: rows before {t0} changed with the rows behind it'
         assert torch.equal(lse_got[:, :, :t0], lse[:, :, :t0]), f'{name}: log-sum-exp before {t0} changed'
         assert not torch.equal(got[:, t0:], out[:, t0:])
-    t0 = s // 2 + 37                     # the loud cut (see the module docstring)
-    other = qkv.clone()
-    other[:, t0:] = (6.0 * torch.randn(b, s - t0, 3, h, d, device=DEV, generator=g)).to(dtype)
-    got, lse_got = _flash(other, scale)
-    assert (got[:, :t0].float() - out[:, :t0].float()).abs().max().item() <= 2.0 ** -6 * out.float().abs().max().item()
-    assert (lse_got[:, :, :t0] - lse[:, :, :t0]).abs().max().item() < 1e-3
-    assert torch.isfinite(got.float()).all() and torch.isfinite(lse_got).all()
+    for t0 in (s // 2 + 37, s - 128 + 5):            # loud rows behind the cut (module docstring)
+        other = qkv.clone()
+        other[:, t0:] = (6.0 * torch.randn(b, s - t0, 3, h, d, device=DEV, generator=g)).to(dtype)
+        got, lse_got = _flash(other, scale)
+        assert torch.isfinite(got.float()).all() and torch.isfinite(lse_got).all()
+        assert torch.equal(got[:, :t0], out[:, :t0]), f'{name}: rows before {t0} changed with the loud rows behind it'
+        assert torch.equal(lse_got[:, :, :t0], lse[:, :, :t0]), f'{name}: log-sum-exp before {t0} changed (loud rows)'
     perm = torch.randperm(b, device=DEV, generator=g)
     got, lse_got = _flash(qkv[perm].contiguous(), scale)
     assert torch.equal(got, out[perm]) and torch.equal(lse_got, lse[perm]), f'{name}: samples are not independent'
@@ -98,20 +97,16 @@ def test_sense_lse_and_mix_causality_sample_independence_determinism(name, b, s,
         got = bp.sense_mix(qk2, c2)
         assert torch.equal(got[:, :t0], out[:, :t0]), f'{name}: mixed rows before {t0} changed with the rows behind it'
         assert not torch.equal(got[:, t0:], out[:, t0:])
-    # the loud cut (module docstring): the LSE pre-pass may answer through its retry branch; with the SAME log-sum-exp
-    # handed in, the mix itself has no such branch and stays bit-exact
-    t0 = s // 2 + 37
-    qk2, c2 = qk.clone(), c.clone()
-    qk2[:, t0:] = (6.0 * torch.randn(b, s - t0, 2, k, dk, device=DEV, generator=g)).to(dtype)
-    c2[:, t0:] = (3.0 * torch.randn(b, s - t0, k, d, device=DEV, generator=g)).to(dtype)
-    lse2 = bp.sense_lse(qk2)
-    assert torch.isfinite(lse2[:, :, :s]).all()
-    assert (lse2[:, :, :t0] - lse[:, :, :t0]).abs().max().item() < 1e-3
-    lse_mixed = lse2.clone()
-    lse_mixed[:, :, :t0] = lse[:, :, :t0]
-    got = bp.sense_mix(qk2, c2, lse=lse_mixed)
-    assert torch.isfinite(got.float()).all()
-    assert torch.equal(got[:, :t0], out[:, :t0]), f'{name}: mixed rows before {t0} changed with the (loud) rows behind it'
+    for t0 in (s // 2 + 37, s - 256 + 5):            # loud rows behind the cut (module docstring)
+        qk2, c2 = qk.clone(), c.clone()
+        qk2[:, t0:] = (6.0 * torch.randn(b, s - t0, 2, k, dk, device=DEV, generator=g)).to(dtype)
+        c2[:, t0:] = (3.0 * torch.randn(b, s - t0, k, d, device=DEV, generator=g)).to(dtype)
+        lse2 = bp.sense_lse(qk2)[:, :, :s]
+        assert torch.isfinite(lse2).all()
+        assert torch.equal(lse2[:, :, :t0], lse[:, :, :t0]), f'{name}: sense LSE before {t0} changed (loud rows)'
+        got = bp.sense_mix(qk2, c2)
+        assert torch.isfinite(got.float()).all()
+        assert torch.equal(got[:, :t0], out[:, :t0]), f'{name}: mixed rows before {t0} changed with the loud rows behind it'
     perm = torch.randperm(b, device=DEV, generator=g)
     assert torch.equal(bp.sense_mix(qk[perm].contiguous(), c[perm].contiguous()), out[perm]), \
         f'{name}: samples are not independent'
@@ -173,27 +168,15 @@ def test_backpack_small_forward_is_causal_at_seq1024(mode):
         hid = t(ids)
         if not torch.equal(hid, t(ids)):
             pytest.skip('the library GEMMs of this box are not run-to-run deterministic: nothing bit-exact to compare')
-        # a cut on a 32-row border: every wave of every kernel lies entirely before or entirely behind it
-        t0 = 576
-        ids2 = ids.clone()
-        ids2[:, t0:] = torch.randint(0, 50257, (8, 1024 - t0), generator=g).to(DEV)
-        hid2 = t(ids2)
-        assert torch.equal(hid2[:, :t0], hid[:, :t0]), 'hidden states before the cut depend on the tokens behind it'
-        assert not torch.equal(hid2[:, t0:], hid[:, t0:])
-        rows = torch.arange(0, t0, 7, device=DEV)
-        assert torch.equal(model.lm_head(hid2[:, rows]), model.lm_head(hid[:, rows]))
-        # a cut inside a wave's 32 rows (544 .. 575): the rows of the waves before it are still the same bits; rows 544 .. 548
-        # share their wave with replaced rows, and the softmax kernels decide their overflow-retry branch per wave (module
-        # docstring; the sharpened weights of this model take it often) -- another rounding, twelve layers deep
-        t0 = 549
-        ids2 = ids.clone()
-        ids2[:, t0:] = torch.randint(0, 50257, (8, 1024 - t0), generator=g).to(DEV)
-        hid2 = t(ids2)
-        assert torch.equal(hid2[:, :544], hid[:, :544]), 'rows of the waves before the cut changed'
-        miss = (hid2[:, 544:t0].float() - hid[:, 544:t0].float()).abs().max().item()
-        print(f'rows 544..548 with {mode!r} content: max |difference| {miss:.3e} of max |hidden| '
-              f'{hid.float().abs().max().item():.2f}')
-        assert miss <= 0.05 * hid.float().abs().max().item()
+        # a cut inside a wave's 32 rows (this model's sharpened weights take the retry branch often) and one on a tile border
+        for t0 in (1024 // 2 + 37, 576):
+            ids2 = ids.clone()
+            ids2[:, t0:] = torch.randint(0, 50257, (8, 1024 - t0), generator=g).to(DEV)
+            hid2 = t(ids2)
+            assert torch.equal(hid2[:, :t0], hid[:, :t0]), f'hidden states before {t0} depend on the tokens behind it'
+            assert not torch.equal(hid2[:, t0:], hid[:, t0:])
+            rows = torch.arange(0, t0, 7, device=DEV)
+            assert torch.equal(model.lm_head(hid2[:, rows]), model.lm_head(hid[:, rows]))
     assert torch.isfinite(hid.float()).all()
 
 

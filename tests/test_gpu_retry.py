@@ -43,7 +43,8 @@ def replay_retries(q, k, scale, causal, limit):
     """Host replay of the kernel's per-wave bookkeeping.  q (S,H,D), k (S,H,D) fp32 (holding 16-bit values).
     Returns [(head, first query of the wave, key tile, largest lane row sum / limit)] for every fast-body tile whose
     validation fails.  Mirrors flash_fwd_tile: wave = 32 queries; tile kb is exact (textbook step) when kb == 0 or
-    kb >= my_clean_end; a lane sums the keys with bit 2 equal to its half-wave over both 32-key halves."""
+    kb >= my_clean_end; a lane sums the keys with bit 2 equal to its half-wave over both 32-key halves; a failed tile is
+    repeated by the whole wave, but only the rows whose own sums failed take its maximum into their reference point."""
     s, h, _ = q.shape
     scores = torch.einsum('thd,shd->hts', q.double(), k.double()) * scale           # natural-log units
     half = ((torch.arange(BN) >> 2) & 1).bool()
@@ -63,6 +64,7 @@ def replay_retries(q, k, scale, causal, limit):
                 if causal:
                     st = st.masked_fill(keys[None, :] > rows[:, None], float('-inf'))
                 exact = kb == 0 or kb >= clean_end
+                moves = torch.ones(len(rows), dtype=torch.bool)
                 if not exact:
                     p = torch.exp(st - m[:, None])
                     lane = torch.stack([p[:, ~half[:len(keys)]].sum(1), p[:, half[:len(keys)]].sum(1)])
@@ -70,8 +72,9 @@ def replay_retries(q, k, scale, causal, limit):
                     if not worst <= limit:
                         events.append((head, q0, kb, worst / limit))
                         exact = True
+                        moves = ~(lane <= limit).all(0)      # in a retry only the rows whose own sums failed move
                 if exact:
-                    m = torch.maximum(m, st.max(1).values)
+                    m = torch.where(moves, torch.maximum(m, st.max(1).values), m)
     return events
 
 
