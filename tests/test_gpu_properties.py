@@ -281,3 +281,79 @@ def test_sense_mix_backward_causality_sample_independence_determinism(name, b, s
         else:
             miss = (dqk0[:, :t0].float() - dqk_t.float()).abs().max().item()
             assert miss <= 2.0 ** -6 * dqk_t.float().abs().max().item(), (name, t0, miss)
+
+
+@pytest.mark.parametrize('h,d,dtype', [(12, 64, torch.bfloat16), (8, 80, torch.bfloat16), (12, 64, torch.float16)],
+                         ids=['small', 'mini', 'small-fp16'])
+def test_flash_ragged_batch_equals_its_sequences_launched_alone(h, d, dtype):
+    """cu_seqlens indexing (reference: csrc/flash_attn/src/fmha_kernel.h:52-57, flash_attn/bert_padding.py:97-117): a ragged
+    batch -- lengths from 1 to 1024, odd ones, some behind others in one buffer -- gives every sequence the BITS it gets as a
+    fixed-length batch of its own, forward (O, LSE) and backward (dQ, dK, dV); the same through strided q / k / v views of one
+    packed (total, 3, H, D) tensor (the qkvpacked entry's layout) and through separate contiguous copies; and the heads of a
+    launch are independent (permuting them permutes the results)."""
+    bp = _bp()
+    g = torch.Generator(device=DEV).manual_seed(41)
+    lens = [1024, 517, 1, 333, 64, 1000, 129, 31]
+    total, smax = sum(lens), max(lens)
+    qkv = torch.randn(total, 3, h, d, device=DEV, generator=g).to(dtype)
+    dout = torch.randn(total, h, d, device=DEV, generator=g).to(dtype)
+    cu = torch.tensor([0] + lens, device=DEV).cumsum(0).to(torch.int32)
+    scale = d ** -0.5
+
+    def run(q, k, v, do, cu_, smax_):
+        out = torch.empty_like(q)
+        lse = bp.flash_fwd(q, k, v, out, cu_, cu_, smax_, smax_, scale, True)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        bp.flash_bwd(do, q, k, v, out, lse, dq, dk, dv, cu_, cu_, smax_, smax_, scale, True)
+        return out, lse, dq, dk, dv
+
+    out, lse, dq, dk, dv = run(qkv[:, 0], qkv[:, 1], qkv[:, 2], dout, cu, smax)
+    for x in (out, dq, dk, dv):
+        assert torch.isfinite(x.float()).all()
+    # contiguous copies instead of the packed tensor's strided views
+    q, k, v = (qkv[:, i].contiguous() for i in range(3))
+    def same_lse(a, c):            # (rows behind a sequence's length are never written)
+        return all(torch.equal(a[i, :, :n], c[i, :, :n]) for i, n in enumerate(lens))
+
+    got = run(q, k, v, dout, cu, smax)
+    assert same_lse(got[1], lse) and all(torch.equal(got[i], c) for i, c in ((0, out), (2, dq), (3, dk), (4, dv))), \
+        'strided views of the packed tensor and contiguous copies differ'
+    start = 0
+    for i, n in enumerate(lens):
+        sl = slice(start, start + n)
+        o1, l1, dq1, dk1, dv1 = run(q[sl].contiguous(), k[sl].contiguous(), v[sl].contiguous(), dout[sl].contiguous(),
+                                    None, n)
+        assert torch.equal(o1, out[sl]) and torch.equal(l1[0, :, :n], lse[i, :, :n]), f'sequence {i} (length {n}): forward'
+        assert torch.equal(dq1, dq[sl]) and torch.equal(dk1, dk[sl]) and torch.equal(dv1, dv[sl]), \
+            f'sequence {i} (length {n}): backward'
+        start += n
+    perm = torch.randperm(h, device=DEV, generator=g)
+    got = run(q[:, perm].contiguous(), k[:, perm].contiguous(), v[:, perm].contiguous(), dout[:, perm].contiguous(), cu, smax)
+    assert torch.equal(got[0], out[:, perm]) and same_lse(got[1], lse[:, perm])
+    assert all(torch.equal(a, c[:, perm]) for a, c in zip(got[2:], (dq, dk, dv)))
+
+
+@pytest.mark.parametrize('name,b,s,k,dk,d,dtype', MIX_SHAPES[:2], ids=[x[0] for x in MIX_SHAPES[:2]])
+def test_forward_kernels_of_a_prefix_equal_the_prefix_of_the_forward(name, b, s, k, dk, d, dtype):
+    """Growing-prefix consistency (the reference's generation loop re-runs the forward on every prefix,
+    training/src/utils/generation.py:64-72): the kernels' results for a sequence cut at t are the first t rows of their
+    results for the whole sequence, bit for bit -- trunk attention (O, LSE), sense LSE and the fused mix; cuts inside a
+    32-key block, on tile borders, at a single row."""
+    bp = _bp()
+    g = torch.Generator(device=DEV).manual_seed(43)
+    h, dh = (12, 64) if d == 768 else (8, 80)
+    qkv = torch.randn(b, s, 3, h, dh, device=DEV, generator=g).to(dtype)
+    qk = (1.5 * torch.randn(b, s, 2, k, dk, device=DEV, generator=g)).to(dtype)
+    c = torch.randn(b, s, k, d, device=DEV, generator=g).to(dtype)
+    scale = dh ** -0.5 / 3
+    out, lse = _flash(qkv, scale)
+    slse = bp.sense_lse(qk)
+    mix = bp.sense_mix(qk, c)
+    for t0 in (s // 2 + 37, s // 2 + 64, s - 256, 200, 1):
+        o_t, l_t = _flash(qkv[:, :t0].contiguous(), scale)
+        assert torch.equal(o_t, out[:, :t0]) and torch.equal(l_t, lse[:, :, :t0]), f'{name}: trunk attention, prefix {t0}'
+        qk_t, c_t = qk[:, :t0].contiguous(), c[:, :t0].contiguous()
+        assert torch.equal(bp.sense_lse(qk_t)[:, :, :t0], slse[:, :, :t0]), f'{name}: sense LSE, prefix {t0}'
+        assert torch.equal(bp.sense_mix(qk_t, c_t), mix[:, :t0]), f'{name}: sense mix, prefix {t0}'
+        # the same through views of the long tensors (strides of the whole sequence, length of the prefix)
+        assert torch.equal(bp.sense_mix(qk[:, :t0], c[:, :t0]), mix[:, :t0]), f'{name}: sense mix on strided views, prefix {t0}'
