@@ -357,3 +357,48 @@ def test_forward_kernels_of_a_prefix_equal_the_prefix_of_the_forward(name, b, s,
         assert torch.equal(bp.sense_mix(qk_t, c_t), mix[:, :t0]), f'{name}: sense mix, prefix {t0}'
         # the same through views of the long tensors (strides of the whole sequence, length of the prefix)
         assert torch.equal(bp.sense_mix(qk[:, :t0], c[:, :t0]), mix[:, :t0]), f'{name}: sense mix on strided views, prefix {t0}'
+
+
+def test_row_wise_kernels_treat_every_row_alone():
+    """The row-wise kernels either side of the attention path (fused add + LayerNorm, fused cross-entropy, bias + GELU), at
+    the bench's row count (64 samples x 1024 positions): a row's result does not depend on where it sits or on how many
+    rows the launch has -- permuting the rows permutes the results, a 7-row slice gives the bits of those rows in the
+    full launch -- and two launches agree."""
+    bp = _bp()
+    g = torch.Generator(device=DEV).manual_seed(51)
+    rows, cols = 64 * 1024, 768
+    x0 = torch.randn(rows, cols, device=DEV, generator=g).bfloat16()
+    x1 = (4.0 * torch.randn(rows, cols, device=DEV, generator=g)).float()
+    w = (1.0 + 0.1 * torch.randn(cols, device=DEV, generator=g)).float()
+    b = (0.1 * torch.randn(cols, device=DEV, generator=g)).float()
+    z, res = bp.add_layer_norm(x0, x1, w, b, 1e-5)
+    z2, res2 = bp.add_layer_norm(x0, x1, w, b, 1e-5)
+    assert torch.equal(z, z2) and torch.equal(res, res2)
+    perm = torch.randperm(rows, device=DEV, generator=g)
+    zp, resp = bp.add_layer_norm(x0[perm].contiguous(), x1[perm].contiguous(), w, b, 1e-5)
+    assert torch.equal(zp, z[perm]) and torch.equal(resp, res[perm])
+    pick = perm[:7]
+    zs, ress = bp.add_layer_norm(x0[pick].contiguous(), x1[pick].contiguous(), w, b, 1e-5)
+    assert torch.equal(zs, z[pick]) and torch.equal(ress, res[pick])
+
+    vocab, n = 50264, 4096                       # the LM head's width, four samples' worth of rows
+    logits = (3.0 * torch.randn(n, vocab, device=DEV, generator=g)).bfloat16()
+    labels = torch.randint(0, vocab, (n,), device=DEV, generator=g)
+    labels[::97] = -100                          # a label outside the vocabulary: no x[label] term, loss 0 without smoothing
+    loss, lse = bp.xentropy_fwd(logits, labels)
+    grad = bp.xentropy_bwd(torch.ones_like(loss), logits, lse, labels)
+    perm = torch.randperm(n, device=DEV, generator=g)
+    loss_p, lse_p = bp.xentropy_fwd(logits[perm].contiguous(), labels[perm])
+    assert torch.equal(loss_p, loss[perm]) and torch.equal(lse_p, lse[perm])
+    assert torch.equal(bp.xentropy_bwd(torch.ones_like(loss), logits[perm].contiguous(), lse_p, labels[perm]), grad[perm])
+    pick = perm[:5]
+    loss_s, lse_s = bp.xentropy_fwd(logits[pick].contiguous(), labels[pick])
+    assert torch.equal(loss_s, loss[pick]) and torch.equal(lse_s, lse[pick])
+    assert torch.count_nonzero(loss[labels == -100]) == 0 and torch.isfinite(lse).all()
+
+    h = torch.randn(rows, 3072, device=DEV, generator=g).bfloat16()
+    bias = torch.randn(3072, device=DEV, generator=g).bfloat16()
+    y = bp.bias_gelu_fwd(h, bias)[0]
+    perm = torch.randperm(rows, device=DEV, generator=g)
+    assert torch.equal(bp.bias_gelu_fwd(h[perm].contiguous(), bias)[0], y[perm])
+    assert torch.equal(bp.bias_gelu_fwd(h[perm[:3]].contiguous(), bias)[0], y[perm[:3]])
