@@ -1,0 +1,151 @@
+"""-m gpu: seeded random-shape sweeps of the hot-path kernels against the oracle.
+
+The fixed sweeps (tests/test_gpu_kernels.py, test_gpu_backward.py, test_gpu_configs.py) walk the reference's own
+parameter grids (tests/test_flash_attn.py:350-373,441-461); the cases here are drawn instead: ragged batches with
+independent query / key lengths (1 ... 700, empty key sequences included), any head dim the entry points take (8 ... 128 in
+steps of 8), 1 ... 5 heads, causal or not, both 16-bit types, a random trunk-layer scale; for the sense kernels 1 ... 20
+senses, d_k from 8 to 64 and the unaligned 10 / 20 / 12, any output width that is a multiple of 8 up to 800, lengths 1 ... 600,
+dense and table (gather) form.  Every case is a fixed function of its seed, so a failure names its shape.  The checker is
+the oracle (oracle/ref_cpu.py) in fp32 on the CPU under the reference's rule: error <= 2 x the error of the same-dtype eager
+op sequence (+ two 16-bit rounding units of the result's range).  (On the CPU on purpose: run on the GPU, the oracle's own
+autograd -- library GEMMs on odd, transposed shapes -- ended a 3000-case hunt with an illegal memory access inside a
+torch kernel, scripts/debug/r05_fuzz_trace.py.)
+"""
+import os
+import random
+
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+SEEDS = range(int(os.environ.get('BP_FUZZ_SEEDS', '24')))      # (a longer hunt: BP_FUZZ_SEEDS=2000 python -m pytest ...)
+
+
+def _bp():
+    import bp_hip
+    return bp_hip
+
+
+def _close(got, ref32, eager, name, factor=2.0, floor=2.0, floor_range=0.0):
+    dtype = got.dtype
+    got, ref32, eager = got.float().cpu(), ref32.float().cpu(), eager.float().cpu()
+    assert torch.isfinite(got).all(), name
+    err = (got - ref32).abs().max().item() if got.numel() else 0.0
+    base = (eager - ref32).abs().max().item() if got.numel() else 0.0
+    # floor: two units of 16-bit rounding at the result's range (tiny drawn cases -- two keys, one head -- leave the eager
+    # yardstick at zero or one ulp, where "twice the eager error" says nothing)
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    ulp = floor * eps * max(ref32.abs().max().item() if got.numel() else 0.0, floor_range)
+    assert err <= factor * base + ulp + 1e-5, f'{name}: {err:.3e} > {factor} x {base:.3e} + {ulp:.1e}'
+
+
+def _grads(q, k, v, dout, causal, scale, upcast):
+    """dq, dk, dv of the oracle's attention for one sequence (1,S,H,D): autograd through oracle/ref_cpu.attention_fp32."""
+    q, k, v = (x.detach().clone().requires_grad_(True) for x in (q, k, v))
+    out = R.attention_fp32(q, k, v, causal=causal, softmax_scale=scale, upcast=upcast, reorder_ops=not upcast)[0]
+    out.backward(dout.to(out.dtype))
+    return q.grad, k.grad, v.grad
+
+
+@pytest.mark.parametrize('seed', SEEDS)
+def test_flash_forward_and_backward_on_drawn_ragged_batches(seed):
+    bp = _bp()
+    rnd = random.Random(1000 + seed)
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    dtype = rnd.choice([torch.bfloat16, torch.float16])
+    causal = rnd.random() < 0.6
+    h, d = rnd.randint(1, 5), 8 * rnd.randint(1, 16)
+    nb = rnd.randint(1, 5)
+    lens_q = [rnd.choice([1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, rnd.randint(1, 700)]) for _ in range(nb)]
+    same = rnd.random() < 0.5
+    lens_k = list(lens_q) if same else [rnd.choice([0, 1, 64, 65, rnd.randint(1, 700)]) for _ in range(nb)]
+    if causal and not same:
+        lens_k = [max(a, c) for a, c in zip(lens_q, lens_k)]      # (causal is top-left aligned; keep every row a key)
+    if sum(lens_k) == 0:
+        lens_k[0] = 1                                             # (a batch without any key row is refused: null pointer)
+    scale = d ** -0.5 / rnd.choice([1, 1, 2, 7, 12])
+    name = f'seed {seed}: {dtype} causal={causal} h={h} d={d} lens_q={lens_q} lens_k={lens_k}'
+    q = torch.randn(sum(lens_q), h, d, device=DEV, generator=g).to(dtype)
+    dout = torch.randn(sum(lens_q), h, d, device=DEV, generator=g).to(dtype)
+    k = torch.randn(max(sum(lens_k), 1), h, d, device=DEV, generator=g).to(dtype)[:sum(lens_k)]
+    v = torch.randn(max(sum(lens_k), 1), h, d, device=DEV, generator=g).to(dtype)[:sum(lens_k)]
+    cu_q = torch.tensor([0] + lens_q, device=DEV).cumsum(0).to(torch.int32)
+    cu_k = torch.tensor([0] + lens_k, device=DEV).cumsum(0).to(torch.int32)
+    out = torch.full_like(q, float('nan'))
+    lse = bp.flash_fwd(q, k, v, out, cu_q, cu_k, max(lens_q), max(max(lens_k), 1), scale, causal)
+    dq, dk, dv = torch.full_like(q, float('nan')), torch.full_like(k, float('nan')), torch.full_like(v, float('nan'))
+    bp.flash_bwd(dout, q, k, v, out, lse, dq, dk, dv, cu_q, cu_k, max(lens_q), max(max(lens_k), 1), scale, causal)
+    for i in range(nb):
+        qs, qe, ks, ke = (int(x) for x in (cu_q[i], cu_q[i + 1], cu_k[i], cu_k[i + 1]))
+        if ke == ks:          # no key: zero output, -inf LSE, zero dq (fmha_fprop_kernel_1xN.h:592-596)
+            assert torch.count_nonzero(out[qs:qe]) == 0 and torch.count_nonzero(dq[qs:qe]) == 0, name
+            assert torch.isinf(lse[i, :, :qe - qs]).all() and (lse[i, :, :qe - qs] < 0).all(), name
+            continue
+        args = (q[None, qs:qe].cpu(), k[None, ks:ke].cpu(), v[None, ks:ke].cpu())
+        ref, _, lse_ref = R.attention_fp32(*(x.float() for x in args), causal=causal, softmax_scale=scale)
+        eager = R.attention_fp32(*args, causal=causal, softmax_scale=scale, upcast=False, reorder_ops=True)[0]
+        _close(out[qs:qe], ref[0], eager[0], name + f' out[{i}]')
+        assert (lse[i, :, :qe - qs].cpu() - lse_ref[0]).abs().max().item() < 4e-3, name + f' lse[{i}]'
+        gref = _grads(*args, dout[None, qs:qe].cpu(), causal, scale, True)
+        geag = _grads(*args, dout[None, qs:qe].cpu(), causal, scale, False)
+        for got, r, e, what in ((dq[qs:qe], gref[0], geag[0], 'dq'), (dk[ks:ke], gref[1], geag[1], 'dk'),
+                                (dv[ks:ke], gref[2], geag[2], 'dv')):
+            # (a handful of keys: dS = P (dP - D) cancels, the error scales with dP ~ |dO| |v|, not with the gradient)
+            short = min(qe - qs, ke - ks) < 32
+            _close(got, r[0], e[0], name + f' {what}[{i}]', floor=8.0 if short else 2.0, floor_range=1.0 if short else 0.0)
+
+
+@pytest.mark.parametrize('seed', SEEDS)
+def test_sense_kernels_on_drawn_shapes(seed):
+    bp = _bp()
+    rnd = random.Random(2000 + seed)
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    dtype = rnd.choice([torch.bfloat16, torch.float16])
+    b = rnd.randint(1, 3)
+    s = rnd.choice([1, 2, 31, 33, 63, 64, 65, 255, 256, 257, rnd.randint(1, 600), rnd.randint(1, 600)])
+    k = rnd.randint(1, 20)
+    dk = rnd.choice([8, 16, 24, 32, 40, 48, 56, 64, 10, 20, 12])
+    d = 8 * rnd.randint(1, 100)
+    name = f'seed {seed}: {dtype} b={b} s={s} k={k} dk={dk} d={d}'
+    qk = (1.3 * torch.randn(b, s, 2, k, dk, device=DEV, generator=g)).to(dtype)
+    c = torch.randn(b, s, k, d, device=DEV, generator=g).to(dtype)
+    scale = dk ** -0.5
+    qk_h, c_h = qk.cpu(), c.cpu()
+    alpha32 = R.sense_alpha_from_qk(qk_h.float())
+    want = R.sense_mix(alpha32, c_h.float().transpose(1, 2))
+    alpha16 = R.sense_alpha_from_qk(qk_h)
+    eager = R.sense_mix(alpha16, c_h.transpose(1, 2))
+    out = bp.sense_mix(qk, c)
+    _close(out, want, eager, name + ' mix')
+    q32, k32 = qk_h[:, :, 0].float(), qk_h[:, :, 1].float()
+    _, _, lse_ref = R.attention_fp32(q32, k32, None, causal=True, softmax_scale=scale)
+    lse = bp.sense_lse(qk)
+    assert (lse[:, :, :s].cpu() - lse_ref).abs().max().item() < 4e-3, name + ' lse'
+    alpha = bp.sense_alpha(qk)
+    _close(alpha, alpha32, alpha16, name + ' alpha')
+    upper = torch.triu(torch.ones(s, s, dtype=torch.bool, device=DEV), 1)
+    assert torch.count_nonzero(alpha[:, :, upper]) == 0, name
+    # table form: a table with repeated and unused rows
+    rows = rnd.randint(1, 300)
+    table = torch.randn(rows, k, d, device=DEV, generator=g).to(dtype)
+    idx = torch.randint(0, rows, (b, s), device=DEV, generator=g, dtype=torch.int32)
+    if bp.sense_mix_gather_supported(qk, table, s):
+        got = bp.sense_mix_gather(qk, table, idx)
+        assert torch.equal(got, bp.sense_mix(qk, table[idx.long()])), name + ' gather'
+    # backward of the contraction (fused kernels where they apply, see bp_hip.SenseMixFn)
+    if dk % 8 == 0:
+        dout = torch.randn(b, s, d, device=DEV, generator=g).to(dtype)
+        qk_g, c_g = qk.clone().requires_grad_(True), c.clone().requires_grad_(True)
+        bp.sense_mix_autograd(qk_g, c_g).backward(dout)
+        grads = {}
+        for tag, cast in (('ref', torch.float32), ('eager', dtype)):
+            qk_r, c_r = qk_h.to(cast).requires_grad_(True), c_h.to(cast).requires_grad_(True)
+            R.sense_mix(R.sense_alpha_from_qk(qk_r), c_r.transpose(1, 2)).backward(dout.cpu().to(cast))
+            grads[tag] = (qk_r.grad, c_r.grad)
+        short = s < 32
+        _close(qk_g.grad, grads['ref'][0], grads['eager'][0], name + ' dqk', factor=3.0, floor=8.0 if short else 2.0,
+               floor_range=1.0 if short else 0.0)
+        _close(c_g.grad, grads['ref'][1], grads['eager'][1], name + ' dC', factor=3.0)
