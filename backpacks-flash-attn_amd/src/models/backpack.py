@@ -16,6 +16,7 @@ its "non-optimized" mode (training/demo_convert.py:7-20).  The flag alone decide
 back silently, and the HIP path raises if its inputs are not 16-bit CUDA tensors.
 """
 import math
+import warnings
 from collections import namedtuple
 from functools import partial
 
@@ -91,6 +92,17 @@ class ContextSelfAttn(nn.Module):
         self.num_content_vectors = num_content_vectors
         self.softmax_scale = None
         self.use_hip = use_hip
+        # The fused sense kernels (LSE pre-pass, alpha, mix, their backward) take sense widths d_k = d / k up to 128 (after
+        # widening to a multiple of 8), like the attention kernels and the reference's own (fmha_api.cpp:245).  The
+        # reference's few-sense ablations lie beyond that -- backpack-mini-flash-vecs-4.yaml: d_k = 160, vecs-1: 640 --
+        # and there alpha is small (k S^2 per sample: 8 MB / 2 MB at S = 1024), so those models run the sense weights and
+        # the combination as the reference's own eager op sequence on the GPU (`fused` False); the trunk stays on the
+        # attention kernels.
+        self.fused = bool(use_hip) and -(-(embed_dim // num_content_vectors) // 8) * 8 <= 128
+        if use_hip and not self.fused:
+            warnings.warn(f'Backpack: {num_content_vectors} sense(s) at width {embed_dim} give d_k = '
+                          f'{embed_dim // num_content_vectors} > 128: the sense weights and their combination run as the '
+                          'eager op sequence on the GPU (the fused HIP kernels cover d_k <= 128); the trunk keeps its HIP kernels')
 
     def project(self, encoded):
         """encoded (B,S,d) -> qk (B,S,2,k,d_k).  On the HIP path a d_k that is not a multiple of 8 (the Mini
@@ -101,7 +113,7 @@ class ContextSelfAttn(nn.Module):
         b, s, d = encoded.shape
         k = self.num_content_vectors
         dk = d // k
-        pad = (-dk) % 8 if self.use_hip else 0
+        pad = (-dk) % 8 if self.fused else 0
         if pad == 0:
             return self.Wqkv(encoded).reshape(b, s, 2, k, dk)
         w, bias = self._padded_projection(k, dk, pad, d)
@@ -141,7 +153,7 @@ class ContextSelfAttn(nn.Module):
 
     def forward(self, encoded):
         qk = self.project(encoded)
-        if self.use_hip:
+        if self.fused:
             return bp_hip.sense_alpha_autograd(qk, self.scale())
         seqlen = qk.shape[1]
         q, k = qk.unbind(dim=2)
@@ -245,6 +257,8 @@ class BackpackModel(GPTPreTrainedModel):
         self.embeddings = self.gpt2_model.embeddings   # shared with the contextualisation model
         self.contextualization_attn = ContextSelfAttn(self.num_content_vectors, config.n_embd,
                                                       use_hip=self.use_hip, **factory_kwargs)
+        # False for the few-sense ablations (d_k > 128) and off the HIP path: eager sense weights + combination
+        self.fused_senses = self.contextualization_attn.fused
 
     @classmethod
     def from_pretrained(cls, model_name, config, *inputs, state_dict=None, **kwargs):
@@ -265,7 +279,7 @@ class BackpackModel(GPTPreTrainedModel):
     # when the row count changes.  Training always runs per position (dropout inside the content network, autograd).
 
     def _token_table_allowed(self, input_ids):
-        return (self.dedup_content and self.sense_table_mode != 'off' and self.use_hip and not self.training
+        return (self.dedup_content and self.sense_table_mode != 'off' and self.fused_senses and not self.training
                 and not torch.is_grad_enabled() and input_ids.is_cuda)
 
     def _dedup_applies(self, input_ids):
@@ -316,7 +330,7 @@ class BackpackModel(GPTPreTrainedModel):
     def refresh_inference_caches(self):
         """Bring the cached sense table up to date with the weights (a no-op when it is); call in front of replaying a
         captured graph of this model after an in-place weight update."""
-        if self.sense_table_mode == 'cached' and self.dedup_content and self.use_hip and not self.training:
+        if self.sense_table_mode == 'cached' and self.dedup_content and self.fused_senses and not self.training:
             self.sense_table()
 
     def train(self, mode=True):
@@ -357,7 +371,7 @@ class BackpackModel(GPTPreTrainedModel):
                 rows, inverse = self._table_of_unique_tokens(input_ids)
                 return self._mix_from_table(contextl_hidden_states, rows, inverse)
         content = self.content_model(input_ids, position_ids, inference_params)   # (B,k,S,d) view
-        if self.use_hip:
+        if self.fused_senses:
             # fused: softmax_causal(q_l k_l^T) @ C_l summed over senses, alpha never stored
             qk = self.contextualization_attn.project(contextl_hidden_states)
             return bp_hip.sense_mix_autograd(qk, content.transpose(1, 2),

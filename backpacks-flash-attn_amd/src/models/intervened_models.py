@@ -66,7 +66,7 @@ class _Intervened(nn.Module, GenerationMixin):
     def _mix(t, hidden, content, key_weight=None):
         """sum_l (alpha_l * key_weight_l) @ content_l; content (B,k,S,d_out), key_weight (B,k,S) or None."""
         attn = t.contextualization_attn
-        if t.use_hip:
+        if t.fused_senses:
             return bp_hip.sense_mix(attn.project(hidden), content.transpose(1, 2), attn.scale(),
                                     key_weight=key_weight)
         alpha = attn(hidden)                                                      # (B,k,S,S)
@@ -143,7 +143,7 @@ class ReplacedWordLMHeadModel(_Intervened):
     def forward(self, input_ids, position_ids=None, inference_params=None):
         t, hidden, content = self._stages(input_ids, position_ids, inference_params)
         content = self.replace_content(input_ids, content)
-        if t.use_hip and content.transpose(1, 2).stride(-1) != 1:
+        if t.fused_senses and content.transpose(1, 2).stride(-1) != 1:
             content = content.contiguous()
         mixed = self._mix(t, hidden, content)
         return CausalLMOutput(logits=self.backpack_network.lm_head(mixed))

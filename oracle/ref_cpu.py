@@ -332,6 +332,10 @@ CONFIGS = {
     'mini': dict(n_embd=640, n_head=8, n_layer=8, num_content_vectors=16),
     'mini-k64': dict(n_embd=640, n_head=8, n_layer=8, num_content_vectors=64,
                      shrink_final_inner=True),
+    # the few-sense ends of the same ablation (training/configs/experiment/owt/backpack-mini-flash-vecs-{4,1}.yaml):
+    # sense widths d_k = 160 and 640
+    'mini-k4': dict(n_embd=640, n_head=8, n_layer=8, num_content_vectors=4, shrink_final_inner=True),
+    'mini-k1': dict(n_embd=640, n_head=8, n_layer=8, num_content_vectors=1, shrink_final_inner=True),
     'small': dict(n_embd=768, n_head=12, n_layer=12, num_content_vectors=16),
 }
 

@@ -141,6 +141,72 @@ def test_mini_k64_config4_whole_model_seq1024():
     _assert_model_parity(run, _hidden(run, run['ids'], 'off'), 'mini-k64 S=1024 per position')
 
 
+@pytest.mark.parametrize('name', ['mini-k4', 'mini-k1'])
+def test_mini_few_sense_ablations_whole_model_seq1024(name):
+    """The few-sense ends of the reference's sense ablation at their REAL size (training/configs/experiment/owt/
+    backpack-mini-flash-vecs-4.yaml: 4 senses of d_k = 160; vecs-1.yaml: one sense of d_k = 640; Mini trunk, vocab 50264,
+    S = 1024, B = 2, bf16).  Their sense width lies beyond what the fused sense kernels take (128), so the model runs the
+    sense weights and the combination as the reference's eager op sequence on the GPU and says so once
+    (`ContextSelfAttn.fused` False); the trunk's eight attention layers stay on the HIP kernels.  Against the fp32 CPU
+    oracle, 3 x rule, in every content mode the config can name (all of them then mean: per position)."""
+    import warnings
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter('always')
+        run = _oracle_run(name)
+    t = run['hip'].transformer
+    assert not t.fused_senses and t.use_hip and any('d_k' in str(w.message) for w in caught)
+    assert t.gpt2_model.layers[0].mixer.use_flash_attn
+    for mode in ('off', 'cached'):
+        _assert_model_parity(run, _hidden(run, run['ids'], mode), f'{name} S=1024 [{mode}]')
+    assert t._sense_table is None                                                  # nothing to cache on this path
+
+
+def test_few_sense_model_trains_on_the_hip_trunk():
+    """A training step of a few-sense model (d_k = 160: eager sense path, HIP trunk, fused LayerNorm / dense layers):
+    loss and every parameter's gradient against fp32 autograd of the eager twin (4 x rule of the config-3 test)."""
+    from src.models.backpack import BackpackConfig, BackpackLMHeadModel
+    import warnings
+    torch.manual_seed(0)
+    kw = dict(n_embd=640, n_head=8, n_layer=2, num_content_vectors=4, vocab_size=1024, n_positions=256,
+              scale_attn_by_inverse_layer_idx=True, shrink_final_inner=True, resid_pdrop=0.0, embd_pdrop=0.0,
+              attn_pdrop=0.0, pad_vocab_size_multiple=8)
+    ref = BackpackLMHeadModel(BackpackConfig(use_flash_attn=False, **kw)).to(DEV).float()
+    with torch.no_grad():
+        ref.transformer.contextualization_attn.Wqkv.weight.mul_(8.0)
+        for layer in ref.transformer.gpt2_model.layers:
+            layer.mixer.Wqkv.weight.mul_(6.0)
+    sd = ref.state_dict()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        hip = BackpackLMHeadModel(BackpackConfig(use_flash_attn=True, fused_dropout_add_ln=True, fused_dense_gelu_dense=True,
+                                                 fused_bias_fc=True, **kw)).to(DEV).float()
+    eager = BackpackLMHeadModel(BackpackConfig(use_flash_attn=False, **kw)).to(DEV).float()
+    hip.load_state_dict(sd)
+    eager.load_state_dict(sd)
+    assert not hip.transformer.fused_senses
+    ids = torch.randint(0, 1024, (2, 256), device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    labels = torch.roll(ids, -1, 1)
+
+    def step(model, autocast):
+        model.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
+            logits = model(ids).logits
+        loss = torch.nn.functional.cross_entropy(logits.float().flatten(0, 1), labels.flatten())
+        loss.backward()
+        return loss.item(), {n: p.grad.float().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    l_ref, g_ref = step(ref.train(), False)
+    l_hip, g_hip = step(hip.train(), True)
+    l_eag, g_eag = step(eager.train(), True)
+    assert abs(l_hip - l_ref) <= 4 * abs(l_eag - l_ref) + 1e-3, (l_hip, l_eag, l_ref)
+    assert set(g_hip) == set(g_ref)
+    for n in g_ref:
+        err = (g_hip[n] - g_ref[n]).abs().max().item()
+        base = (g_eag[n] - g_ref[n]).abs().max().item()
+        assert torch.isfinite(g_hip[n]).all(), n
+        assert err <= 4 * base + 1e-4 * max(1.0, g_ref[n].abs().max().item()), (n, err, base)
+
+
 def test_sense_table_follows_the_weights_and_survives_graph_capture():
     """The cached whole-vocabulary table: equal to the per-position order at B = 1 and B = 4 (up to the BLAS rounding of a
     row when the row count of the content GEMMs changes); rebuilt IN PLACE (same storage) after an in-place weight

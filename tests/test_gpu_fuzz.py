@@ -149,3 +149,65 @@ def test_sense_kernels_on_drawn_shapes(seed):
         _close(qk_g.grad, grads['ref'][0], grads['eager'][0], name + ' dqk', factor=3.0, floor=8.0 if short else 2.0,
                floor_range=1.0 if short else 0.0)
         _close(c_g.grad, grads['ref'][1], grads['eager'][1], name + ' dC', factor=3.0)
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('BP_FUZZ_MODELS', '10'))))
+def test_whole_model_on_drawn_configurations(seed):
+    """ids -> hidden states -> logits of Backpack models whose dimensions are drawn (width, heads, layers, senses --
+    including widths whose d_k = d / k is not a multiple of 8, e.g. 10, 12, 20 --, `shrink_final_inner`, vocabulary,
+    positions, batch, length, dtype, the reference's fused-flag set on or off), on the HIP path, against the oracle's fp32
+    forward of the same state dict; the reference's model-test rule: error <= 3 x the error of the same model in eager
+    16 bit (+1e-3); and the three content orders of the inference forward agree with each other to that accuracy."""
+    from src.models.backpack import BackpackConfig, BackpackLMHeadModel
+    rnd = random.Random(3000 + seed)
+    dtype = rnd.choice([torch.bfloat16, torch.float16])
+    dh = rnd.choice([16, 32, 40, 64, 80])
+    nh = rnd.randint(1, 4)
+    d = dh * nh
+    k = rnd.choice([x for x in (1, 2, 4, 5, 8, 16) if d % x == 0])
+    ocfg = dict(n_embd=d, n_head=nh, n_layer=rnd.randint(1, 3), num_content_vectors=k,
+                shrink_final_inner=rnd.random() < 0.5, n_positions=rnd.choice([64, 130, 257]),
+                vocab_size=8 * rnd.randint(8, 60), layer_norm_epsilon=1e-5, scale_attn_by_inverse_layer_idx=True)
+    b, s = rnd.randint(1, 3), rnd.randint(1, ocfg['n_positions'])
+    fused = rnd.random() < 0.7
+    name = f'seed {seed}: {dtype} d={d} heads={nh} k={k} (d_k={d // k}) {ocfg} b={b} s={s} fused={fused}'
+    sd = R.init_state_dict(ocfg, seed=seed)
+    with torch.no_grad():
+        sd['transformer.contextualization_attn.Wqkv.weight'].mul_(8.0)
+        for i in range(ocfg['n_layer']):
+            sd[f'transformer.gpt2_model.layers.{i}.mixer.Wqkv.weight'].mul_(6.0)
+        sd = {key: v.to(dtype).float() for key, v in sd.items()}        # 16-bit-exact weights for all three runs
+    sd['lm_head.weight'] = sd['transformer.gpt2_model.embeddings.word_embeddings.weight']
+    ids = torch.randint(0, ocfg['vocab_size'], (b, s), generator=torch.Generator().manual_seed(seed))
+    with torch.no_grad():
+        want = R.backpack_forward(sd, ocfg, ids, return_stages=True)
+
+    def build(use_flash, fused_):
+        cfg = BackpackConfig(n_embd=d, n_head=nh, n_layer=ocfg['n_layer'], num_content_vectors=k,
+                             vocab_size=ocfg['vocab_size'], n_positions=ocfg['n_positions'],
+                             scale_attn_by_inverse_layer_idx=True, shrink_final_inner=ocfg['shrink_final_inner'],
+                             resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0, use_flash_attn=use_flash,
+                             fused_dropout_add_ln=fused_, fused_dense_gelu_dense=fused_, fused_bias_fc=fused_,
+                             pad_vocab_size_multiple=8)
+        m = BackpackLMHeadModel(cfg)
+        res = m.load_state_dict(sd, strict=False)
+        assert not res.unexpected_keys and all('embeddings' in x for x in res.missing_keys), (name, res)
+        m.tie_weights()
+        return m.to(DEV, dtype).eval()
+
+    hip, eager = build(True, fused), build(False, False)
+    dev_ids = ids.to(DEV)
+    with torch.no_grad():
+        base_h = eager.transformer(dev_ids)
+        base_l = eager.lm_head(base_h)
+        results = {}
+        for mode in ('off', 'cached', 'batch'):
+            hip.transformer.sense_table_mode = mode
+            h = hip.transformer(dev_ids)
+            results[mode] = (h, hip.lm_head(h))
+    for mode, (h, logits) in results.items():
+        for got, base, ref, what in ((h, base_h, want['hidden'], 'hidden'), (logits, base_l, want['logits'], 'logits')):
+            err = (got.float().cpu() - ref).abs().max().item()
+            yard = (base.float().cpu() - ref).abs().max().item()
+            assert torch.isfinite(got.float()).all(), name
+            assert err <= 3 * yard + 1e-3, f'{name} [{mode}] {what}: {err:.3e} > 3 x {yard:.3e}'
