@@ -211,3 +211,62 @@ def test_whole_model_on_drawn_configurations(seed):
             yard = (base.float().cpu() - ref).abs().max().item()
             assert torch.isfinite(got.float()).all(), name
             assert err <= 3 * yard + 1e-3, f'{name} [{mode}] {what}: {err:.3e} > 3 x {yard:.3e}'
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('BP_FUZZ_TRAIN', '8'))))
+def test_training_step_on_drawn_configurations(seed):
+    """One training step (forward under 16-bit autocast with fp32 parameters -- the reference's recipe, training/configs/
+    experiment/owt/base.yaml -- loss, backward) of drawn Backpack models on the HIP path, dropout off: the loss and EVERY
+    parameter's gradient against fp32 autograd of the eager twin (use_flash_attn and the fused flags off, the op sequence
+    the CPU tests pin against the oracle), measured with the twin's own 16-bit autocast step: error <= 4 x its error."""
+    import warnings
+    from src.models.backpack import BackpackConfig, BackpackLMHeadModel
+    rnd = random.Random(4000 + seed)
+    amp = rnd.choice([torch.bfloat16, torch.float16])
+    dh = rnd.choice([16, 32, 40, 64, 80, 128])
+    nh = rnd.randint(1, 3)
+    d = dh * nh
+    k = rnd.choice([x for x in (1, 2, 4, 5, 8, 16, 32) if d % x == 0])
+    kw = dict(n_embd=d, n_head=nh, n_layer=rnd.randint(1, 3), num_content_vectors=k, vocab_size=8 * rnd.randint(8, 60),
+              n_positions=rnd.choice([64, 130, 257]), scale_attn_by_inverse_layer_idx=True,
+              shrink_final_inner=rnd.random() < 0.5, resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0,
+              pad_vocab_size_multiple=8)
+    b, s = rnd.randint(1, 3), rnd.randint(2, kw['n_positions'])
+    fused = rnd.random() < 0.7
+    name = f'seed {seed}: amp={amp} d_k={d // k} {kw} b={b} s={s} fused={fused}'
+    torch.manual_seed(seed)
+    ref = BackpackLMHeadModel(BackpackConfig(use_flash_attn=False, **kw)).to(DEV).float()
+    with torch.no_grad():
+        ref.transformer.contextualization_attn.Wqkv.weight.mul_(6.0)
+        for layer in ref.transformer.gpt2_model.layers:
+            layer.mixer.Wqkv.weight.mul_(4.0)
+    sd = ref.state_dict()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        hip = BackpackLMHeadModel(BackpackConfig(use_flash_attn=True, fused_dropout_add_ln=fused, fused_dense_gelu_dense=fused,
+                                                 fused_bias_fc=fused, **kw)).to(DEV).float()
+    eager = BackpackLMHeadModel(BackpackConfig(use_flash_attn=False, **kw)).to(DEV).float()
+    hip.load_state_dict(sd)
+    eager.load_state_dict(sd)
+    ids = torch.randint(0, kw['vocab_size'], (b, s), device=DEV, generator=torch.Generator(device=DEV).manual_seed(seed))
+    labels = torch.roll(ids, -1, 1)
+
+    def step(model, autocast):
+        model.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=amp, enabled=autocast):
+            logits = model(ids).logits
+        loss = torch.nn.functional.cross_entropy(logits.float().flatten(0, 1), labels.flatten())
+        loss.backward()
+        return loss.item(), {n: p.grad.float().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    l_ref, g_ref = step(ref.train(), False)
+    l_hip, g_hip = step(hip.train(), True)
+    l_eag, g_eag = step(eager.train(), True)
+    assert abs(l_hip - l_ref) <= 4 * abs(l_eag - l_ref) + 2e-3, (name, l_hip, l_eag, l_ref)
+    assert set(g_hip) == set(g_ref), name
+    for n in g_ref:
+        err = (g_hip[n] - g_ref[n]).abs().max().item()
+        base = (g_eag[n] - g_ref[n]).abs().max().item()
+        assert torch.isfinite(g_hip[n]).all(), (name, n)
+        floor = (2.0 ** -8 if amp == torch.bfloat16 else 2.0 ** -11) * max(1e-2, g_ref[n].abs().max().item())
+        assert err <= 4 * base + floor, f'{name} grad {n}: {err:.3e} > 4 x {base:.3e} + {floor:.1e}'
