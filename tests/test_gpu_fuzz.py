@@ -270,3 +270,69 @@ def test_training_step_on_drawn_configurations(seed):
         assert torch.isfinite(g_hip[n]).all(), (name, n)
         floor = (2.0 ** -8 if amp == torch.bfloat16 else 2.0 ** -11) * max(1e-2, g_ref[n].abs().max().item())
         assert err <= 4 * base + floor, f'{name} grad {n}: {err:.3e} > 4 x {base:.3e} + {floor:.1e}'
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('BP_FUZZ_INTERVENE', '8'))))
+def test_intervened_models_on_drawn_configurations(seed):
+    """The paper's control experiments (training/src/models/intervened_models.py) on drawn Backpack configurations, few-sense
+    ones (eager sense path) and padded sense widths included: per-token sense re-weighting through the kernel's key-weight
+    hook, with and without annealing; the negative re-weighting on vocabulary-sized content; replaced sense vectors -- HIP
+    path in 16 bit against the oracle's fp32 restatements, 3 x the eager 16-bit twin's error (+2e-3)."""
+    import warnings
+    from src.models import intervened_models as im
+    from src.models.backpack import BackpackConfig, BackpackLMHeadModel
+    rnd = random.Random(5000 + seed)
+    dtype = rnd.choice([torch.bfloat16, torch.float16])
+    dh = rnd.choice([16, 32, 40, 64, 80])
+    nh = rnd.randint(1, 3)
+    d = dh * nh
+    k = rnd.choice([x for x in (1, 2, 4, 5, 8, 16) if d % x == 0])
+    vocab = 8 * rnd.randint(8, 40)
+    ocfg = dict(n_embd=d, n_head=nh, n_layer=rnd.randint(1, 2), num_content_vectors=k, shrink_final_inner=rnd.random() < 0.5,
+                n_positions=rnd.choice([32, 70, 130]), vocab_size=vocab, layer_norm_epsilon=1e-5,
+                scale_attn_by_inverse_layer_idx=True)
+    b, s = rnd.randint(1, 3), rnd.randint(2, ocfg['n_positions'])
+    name = f'seed {seed}: {dtype} d_k={d // k} {ocfg} b={b} s={s}'
+    g = torch.Generator().manual_seed(seed)
+    sd = {key: v.to(dtype).float() for key, v in R.init_state_dict(ocfg, seed=seed).items()}
+    sd['transformer.contextualization_attn.Wqkv.weight'] = sd['transformer.contextualization_attn.Wqkv.weight'] * 4.0
+    sd['lm_head.weight'] = sd['transformer.gpt2_model.embeddings.word_embeddings.weight']
+    ids = torch.randint(0, vocab, (b, s), generator=g)
+    cw = (torch.rand(vocab, k, generator=g) * 2.0).to(dtype).float()          # (vocab, senses) content weights
+    words = sorted({int(x) for x in ids.flatten()[:3]})
+    senses = {w: torch.randn(k, d, generator=g).to(dtype).float() * 0.1 for w in words}
+    scale = 0.1
+
+    def build(use_flash):
+        cfg = BackpackConfig(n_embd=d, n_head=nh, n_layer=ocfg['n_layer'], num_content_vectors=k, vocab_size=vocab,
+                             n_positions=ocfg['n_positions'], scale_attn_by_inverse_layer_idx=True,
+                             shrink_final_inner=ocfg['shrink_final_inner'], resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0,
+                             use_flash_attn=use_flash, pad_vocab_size_multiple=8)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            m = BackpackLMHeadModel(cfg)
+        res = m.load_state_dict(sd, strict=False)
+        assert not res.unexpected_keys, (name, res)
+        m.tie_weights()
+        return m.eval()
+
+    hip = build(True).to(DEV, dtype)
+    eager = build(False).to(dtype)
+    cases = [('weighted, annealed', im.WeightedBackpackLMHeadModel, R.weighted_backpack_logits, dict(anneal=True)),
+             ('weighted', im.WeightedBackpackLMHeadModel, R.weighted_backpack_logits, dict(anneal=False)),
+             ('negative, annealed', im.NegativeWeightedBackpackLMHeadModel, R.negative_weighted_backpack_logits, dict(anneal=True)),
+             ('negative', im.NegativeWeightedBackpackLMHeadModel, R.negative_weighted_backpack_logits, dict(anneal=False))]
+    with torch.no_grad():
+        for what, cls, oracle, opt in cases:
+            want = oracle(sd, ocfg, ids, cw, annealing_scale=scale, **opt)
+            got = cls(hip, cw.to(DEV), torch.zeros(vocab), scale, **opt)(ids.to(DEV)).logits
+            base = cls(eager, cw, torch.zeros(vocab), scale, **opt)(ids).logits
+            err = (got.float().cpu() - want).abs().max().item()
+            yard = (base.float() - want).abs().max().item()
+            assert torch.isfinite(got.float()).all(), (name, what)
+            assert err <= 3 * yard + 2e-3, f'{name} [{what}]: {err:.3e} > 3 x {yard:.3e}'
+        want = R.replaced_word_logits(sd, ocfg, ids, senses)
+        got = im.ReplacedWordLMHeadModel(hip, senses)(ids.to(DEV)).logits
+        base = im.ReplacedWordLMHeadModel(eager, senses)(ids).logits
+        err, yard = (got.float().cpu() - want).abs().max().item(), (base.float() - want).abs().max().item()
+        assert err <= 3 * yard + 2e-3, f'{name} [replaced]: {err:.3e} > 3 x {yard:.3e}'
