@@ -402,3 +402,37 @@ def test_row_wise_kernels_treat_every_row_alone():
     perm = torch.randperm(rows, device=DEV, generator=g)
     assert torch.equal(bp.bias_gelu_fwd(h[perm].contiguous(), bias)[0], y[perm])
     assert torch.equal(bp.bias_gelu_fwd(h[perm[:3]].contiguous(), bias)[0], y[perm[:3]])
+
+
+def test_operands_as_awkward_views():
+    """Views whose element offset breaks the 16-byte alignment or whose row / head strides are not multiples of eight (slices
+    of wider buffers): the attention forward and the fused sense mix give the contiguous call's result -- the aligned ones
+    bit for bit (same kernel), the others through the generic kernels, to 16-bit rounding -- and never fault."""
+    bp = _bp()
+    g = torch.Generator(device=DEV).manual_seed(61)
+    for (b, s, h, d) in ((2, 100, 3, 64), (1, 257, 2, 40), (2, 64, 1, 128), (1, 33, 4, 16)):
+        for off in (0, 1, 3, 4, 8):
+            for gap in (0, 1, 5, 8):
+                big = torch.randn(b * s, 3, h, d + gap + off + 8, device=DEV, generator=g).bfloat16()
+                q, k, v = (big[:, i, :, off:off + d] for i in range(3))
+                want = torch.empty(b * s, h, d, device=DEV, dtype=torch.bfloat16)
+                lse_want = bp.flash_fwd(q.contiguous(), k.contiguous(), v.contiguous(), want, None, None, s, s, d ** -0.5, True)
+                got = torch.full_like(want, float('nan'))
+                lse = bp.flash_fwd(q, k, v, got, None, None, s, s, d ** -0.5, True)
+                tag = f'flash {(b, s, h, d)} offset {off} gap {gap}'
+                assert (got.float() - want.float()).abs().max().item() < 2e-2, tag
+                assert (lse[:, :, :s] - lse_want[:, :, :s]).abs().max().item() < 4e-3, tag
+                if off % 8 == 0 and (d + gap + off + 8) % 8 == 0:
+                    assert torch.equal(got, want), tag
+    for (b, s, k, dk, d) in ((2, 100, 4, 48, 256), (1, 65, 3, 24, 104), (1, 200, 16, 16, 64)):
+        for off in (0, 1, 4, 8):
+            for gap in (0, 3, 8):
+                bigqk = torch.randn(b, s, 2, k, dk + gap + off + 8, device=DEV, generator=g).bfloat16()
+                bigc = torch.randn(b, s, k, d + gap + off + 8, device=DEV, generator=g).bfloat16()
+                qk, c = bigqk[..., off:off + dk], bigc[..., off:off + d]
+                want = bp.sense_mix(qk.contiguous(), c.contiguous())
+                got = bp.sense_mix(qk, c)
+                tag = f'mix {(b, s, k, dk, d)} offset {off} gap {gap}'
+                assert (got.float() - want.float()).abs().max().item() < 2e-2, tag
+                if off % 8 == 0 and gap % 8 == 0:
+                    assert torch.equal(got, want), tag
