@@ -425,14 +425,33 @@ def sense_mix(qk, content, softmax_scale=None, out=None, lse=None, key_weight=No
     return out
 
 
+SENSE_MAX_DK = 640     # widest sense bp_sense_lse / _alpha / _mix take (include/bp_hip.h; > 128: csrc/sense_wide.hip)
+
+
 def sense_mix_gather_supported(qk, table, seqlen):
     """Shapes bp_sense_mix_gather takes (include/bp_hip.h): the 16-byte vector path, seqlen <= 4096, at most 65 536 table
     rows (any GPT-2 vocabulary), 32-bit byte offsets into the table."""
     dk = round_up(qk.shape[-1], 8)
-    return (qk.is_cuda and table.is_cuda and table.dim() == 3 and table.stride(-1) == 1 and table.shape[2] % 8 == 0
+    return (dk <= 128 and qk.is_cuda and table.is_cuda and table.dim() == 3 and table.stride(-1) == 1 and table.shape[2] % 8 == 0
             and table.stride(0) % 8 == 0 and table.stride(1) % 8 == 0 and table.data_ptr() % 16 == 0
             and seqlen <= 4096 and table.shape[0] <= 65536
             and table.shape[0] * table.stride(0) * table.element_size() < 2 ** 32)
+
+
+def sense_mix_gather_limits(qk, table, seqlen):
+    """Which limit of bp_sense_mix_gather a call exceeds, as text (callers log it when they fall back to a torch gather)."""
+    why = []
+    if round_up(qk.shape[-1], 8) > 128:
+        why.append(f'sense width {qk.shape[-1]} > 128 (wide senses take the dense kernel)')
+    if seqlen > 4096:
+        why.append(f'sequence length {seqlen} > 4096 (a job keeps its keys\' row indices in LDS)')
+    if table.shape[0] > 65536:
+        why.append(f'{table.shape[0]} table rows > 65536 (u16 row indices)')
+    if table.shape[0] * table.stride(0) * table.element_size() >= 2 ** 32:
+        why.append('table of 4 GiB or more (32-bit byte offsets)')
+    if not why:
+        why.append('table layout (last dim contiguous, 16-byte aligned rows, d % 8 == 0 required)')
+    return '; '.join(why)
 
 
 def sense_mix_gather(qk, table, row_index, softmax_scale=None, out=None, lse=None):
@@ -625,7 +644,8 @@ def sense_dqk(qk, content, dout, lse, softmax_scale):
 
 
 def _fused_mix_backward_ok(qk, content, key_weight):
-    return (key_weight is None and qk.shape[-1] % 8 == 0 and content.shape[-1] % 8 == 0 and qk.is_contiguous()
+    return (key_weight is None and qk.shape[-1] % 8 == 0 and qk.shape[-1] <= 128 and content.shape[-1] % 8 == 0
+            and qk.is_contiguous()
             and content.stride(-1) == 1 and content.stride(2) == content.shape[-1]
             and content.stride(1) == content.shape[2] * content.shape[-1]
             and content.stride(0) == content.shape[1] * content.stride(1) and qk.shape[1] <= 65536)
@@ -656,7 +676,10 @@ class SenseMixFn(torch.autograd.Function):
         qk, content, lse, key_weight = ctx.saved_tensors
         dout = dout.contiguous()
         if not _fused_mix_backward_ok(qk, content, key_weight):
-            if not eager_fallback_allowed(ctx):
+            # wide senses (128 < d_k <= 640: csrc/sense_wide.hip) have no fused backward and need none: with few senses
+            # alpha is small (k S^2 per sample), so the alpha-rebuilding route IS their backward -- no opt-in asked
+            wide = key_weight is None and qk.shape[-1] > 128
+            if not wide and not eager_fallback_allowed(ctx):
                 raise RuntimeError(
                     'bp_hip.SenseMixFn.backward: the fused backward kernels take d_k % 8 == 0, d_out % 8 == 0, a contiguous '
                     '(B,S,k,d) content and no key_weight; this call would take the alpha-rebuilding route (two (B,k,S,S) '
@@ -925,11 +948,28 @@ class GraphedForward:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph), torch.no_grad():
             self.static_out = select(module(self.static_in))
+        # The captured kernels hold the ADDRESS of such a cache.  Pin its storage (BackpackModel.train() would otherwise
+        # free the table, and the refresh after the next eval() would build it somewhere else) and remember it: a replay
+        # whose refresh did not land in this storage is refused instead of reading a freed block.
+        self._pinned = []
+        for m in module.modules():
+            if hasattr(m, 'pin_sense_table') and getattr(m, '_sense_table', None) is not None:
+                m.pin_sense_table()
+                self._pinned.append((m, m._sense_table[1]))
+        self.module = module
 
     def __call__(self, x):
+        if self.module.training and self._pinned:
+            raise RuntimeError('bp_hip.GraphedForward: the graph was captured in eval mode with the cached sense table; '
+                               'call module.eval() before replaying it')
         self.static_in.copy_(x)
         if self.refresh is not None:
             with torch.no_grad():
                 self.refresh()
+        for m, table in self._pinned:
+            now = m._sense_table[1] if m._sense_table is not None else None
+            if now is None or now.data_ptr() != table.data_ptr() or m._sense_table[0] is None:
+                raise RuntimeError('bp_hip.GraphedForward: the sense table the graph reads was replaced or could not be '
+                                   'refreshed in place; capture a new GraphedForward')
         self.graph.replay()
         return self.static_out

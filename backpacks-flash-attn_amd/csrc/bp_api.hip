@@ -77,7 +77,7 @@ const char *bp_strerror(int code) {
     switch (code) {
         case BP_OK: return "ok";
         case BP_ERR_DTYPE: return "unsupported dtype (expected fp16 or bf16)";
-        case BP_ERR_HEAD_DIM: return "head dimension must be in [1, 128]";
+        case BP_ERR_HEAD_DIM: return "head dimension must be in [1, 128] (sense width of bp_sense_lse / _alpha / _mix: [1, 640])";
         case BP_ERR_SHAPE: return "invalid shape or null pointer";
         case BP_ERR_SCALE: return "softmax_scale must be finite and > 0";
         case BP_ERR_LAUNCH: return "HIP kernel launch failed";
@@ -222,7 +222,11 @@ static int sense_lse(const void *qk, float *lse_ws, int batch, int seqlen, int n
     p.scale_log2e = softmax_scale * bp::kLog2e;
     const bool vec = (d_k % 8 == 0) && aligned16(qp) && aligned16(kp) && mult8(qk_bs) && mult8(qk_rs) &&
                      mult8(qk_ss);
-    hipError_t e = dispatch_flash(p, dtype, vec, stream);
+    hipError_t e;
+    if (d_k > 128)   // wide senses (sense_wide.hip): the reference's vecs-4 / vecs-1 ablations
+        e = bp::launch_sense_lse_wide(qp, kp, lse_ws, p.lse_stride, qk_bs, qk_rs, qk_ss, batch, seqlen, nsenses, d_k,
+                                      p.scale_log2e, dtype, vec, stream);
+    else e = dispatch_flash(p, dtype, vec, stream);
     return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
 }
 
@@ -230,7 +234,7 @@ int bp_sense_lse(const void *qk, float *lse, int batch, int seqlen, int nsenses,
                  int64_t qk_batch_stride, int64_t qk_row_stride, int64_t qk_two_stride,
                  int64_t qk_sense_stride, float softmax_scale, int dtype, bp_stream_t stream) {
     if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
-    if (d_k < 1 || d_k > 128) return BP_ERR_HEAD_DIM;
+    if (d_k < 1 || d_k > bp::kWideMaxDk) return BP_ERR_HEAD_DIM;
     if (batch <= 0 || nsenses <= 0 || seqlen <= 0) return BP_ERR_SHAPE;
     if (qk == nullptr || lse == nullptr) return BP_ERR_SHAPE;
     if (!scale_ok(softmax_scale)) return BP_ERR_SCALE;
@@ -244,7 +248,7 @@ int bp_sense_alpha(const void *qk, void *alpha, float *lse_ws, int lse_ready,
                    int64_t qk_batch_stride, int64_t qk_row_stride, int64_t qk_two_stride,
                    int64_t qk_sense_stride, float softmax_scale, int dtype, bp_stream_t stream) {
     if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
-    if (d_k < 1 || d_k > 128) return BP_ERR_HEAD_DIM;
+    if (d_k < 1 || d_k > bp::kWideMaxDk) return BP_ERR_HEAD_DIM;
     if (batch <= 0 || nsenses <= 0 || seqlen <= 0) return BP_ERR_SHAPE;
     if (qk == nullptr || alpha == nullptr || lse_ws == nullptr) return BP_ERR_SHAPE;
     if (!scale_ok(softmax_scale)) return BP_ERR_SCALE;
@@ -256,6 +260,15 @@ int bp_sense_alpha(const void *qk, void *alpha, float *lse_ws, int lse_ready,
     }
     const uint16_t *qp = static_cast<const uint16_t *>(qk);
     const int64_t S = seqlen;
+    if (d_k > 128) {
+        const uint16_t *kp = qp + qk_two_stride;
+        const bool vec = (d_k % 8 == 0) && aligned16(qp) && aligned16(kp) && mult8(qk_batch_stride) &&
+                         mult8(qk_row_stride) && mult8(qk_sense_stride);
+        const hipError_t e = bp::launch_sense_alpha_wide(qp, kp, lse_ws, round_up(seqlen, 16), alpha, qk_batch_stride,
+                                                         qk_row_stride, qk_sense_stride, batch, seqlen, nsenses, d_k,
+                                                         softmax_scale * bp::kLog2e, dtype, vec, st);
+        return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
+    }
     return bp_attn_probs(qp, qp + qk_two_stride, lse_ws, alpha, batch, nsenses, d_k, seqlen, seqlen,
                          qk_batch_stride, qk_row_stride, qk_sense_stride,
                          qk_batch_stride, qk_row_stride, qk_sense_stride,
@@ -287,7 +300,7 @@ int bp_sense_mix_weighted(const void *qk, const void *content, const float *key_
                           int64_t o_batch_stride, int64_t o_row_stride,
                           float softmax_scale, int dtype, void *queue_ws, bp_stream_t stream) {
     if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
-    if (d_k < 1 || d_k > 128) return BP_ERR_HEAD_DIM;
+    if (d_k < 1 || d_k > bp::kWideMaxDk) return BP_ERR_HEAD_DIM;
     if (queue_ws != nullptr && !aligned16(queue_ws)) return BP_ERR_SHAPE;
     if (d_out < 1) return BP_ERR_DOUT;
     if (batch <= 0 || nsenses <= 0 || seqlen <= 0) return BP_ERR_SHAPE;
@@ -320,7 +333,8 @@ int bp_sense_mix_weighted(const void *qk, const void *content, const float *key_
                        mult8(c_row_stride) && mult8(c_sense_stride) && mult8(o_batch_stride) &&
                        mult8(o_row_stride);
     hipError_t e;
-    if (vec_qk && vec_c && p.n_qtiles <= 256 && !dev_force_staged_mix()) e = bp::launch_sense_mix_dma(p, dtype, st);
+    if (d_k > 128) e = bp::launch_sense_mix_wide(p, dtype, vec_qk, vec_c, st);   // few wide senses: sense_wide.hip
+    else if (vec_qk && vec_c && p.n_qtiles <= 256 && !dev_force_staged_mix()) e = bp::launch_sense_mix_dma(p, dtype, st);
     else e = bp::launch_sense_mix(p, dtype, vec_qk, vec_c, st);
     return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
 }

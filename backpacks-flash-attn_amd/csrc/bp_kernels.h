@@ -220,5 +220,14 @@ hipError_t launch_attn_probs(const ProbsParams &p, int dtype, bool vec, hipStrea
 hipError_t launch_sense_mix(const MixParams &p, int dtype, bool vec_qk, bool vec_c, hipStream_t stream);
 // LDS-DMA ring version; needs 16-byte friendly shapes (vec_qk && vec_c)
 hipError_t launch_sense_mix_dma(const MixParams &p, int dtype, hipStream_t stream);
+// wide senses, 128 < d_k <= kWideMaxDk (sense_wide.hip): the reference's few-sense ablations (vecs-4: 160, vecs-1: 640)
+constexpr int kWideMaxDk = 640;
+hipError_t launch_sense_lse_wide(const void *q, const void *k, float *lse, int64_t lse_stride, int64_t qk_bs,
+                                 int64_t qk_rs, int64_t qk_ss, int b, int s, int nsenses, int dk, float scale_log2e,
+                                 int dtype, bool vec, hipStream_t stream);
+hipError_t launch_sense_alpha_wide(const void *q, const void *k, float *lse, int64_t lse_stride, void *alpha,
+                                   int64_t qk_bs, int64_t qk_rs, int64_t qk_ss, int b, int s, int nsenses, int dk,
+                                   float scale_log2e, int dtype, bool vec, hipStream_t stream);
+hipError_t launch_sense_mix_wide(const MixParams &p, int dtype, bool vec_qk, bool vec_c, hipStream_t stream);
 
 }  // namespace bp

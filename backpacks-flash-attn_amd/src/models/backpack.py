@@ -92,17 +92,17 @@ class ContextSelfAttn(nn.Module):
         self.num_content_vectors = num_content_vectors
         self.softmax_scale = None
         self.use_hip = use_hip
-        # The fused sense kernels (LSE pre-pass, alpha, mix, their backward) take sense widths d_k = d / k up to 128 (after
-        # widening to a multiple of 8), like the attention kernels and the reference's own (fmha_api.cpp:245).  The
-        # reference's few-sense ablations lie beyond that -- backpack-mini-flash-vecs-4.yaml: d_k = 160, vecs-1: 640 --
-        # and there alpha is small (k S^2 per sample: 8 MB / 2 MB at S = 1024), so those models run the sense weights and
-        # the combination as the reference's own eager op sequence on the GPU (`fused` False); the trunk stays on the
-        # attention kernels.
-        self.fused = bool(use_hip) and -(-(embed_dim // num_content_vectors) // 8) * 8 <= 128
+        # Sense widths d_k = d / k: up to 128 (after widening to a multiple of 8) the LDS-DMA kernels and the fused backward;
+        # 129 ... 640 -- the reference's few-sense ablations, backpack-mini-flash-vecs-4.yaml: d_k = 160, vecs-1: 640 -- the
+        # wide kernels of csrc/sense_wide.hip (forward fused as well; backward through the alpha-rebuilding route, alpha
+        # being small with few senses: k S^2 per sample).  Beyond 640 (no reference config) the reference's own eager op
+        # sequence runs on the GPU, with one warning; the trunk keeps its kernels either way.
+        self.fused = bool(use_hip) and -(-(embed_dim // num_content_vectors) // 8) * 8 <= bp_hip.SENSE_MAX_DK
         if use_hip and not self.fused:
             warnings.warn(f'Backpack: {num_content_vectors} sense(s) at width {embed_dim} give d_k = '
-                          f'{embed_dim // num_content_vectors} > 128: the sense weights and their combination run as the '
-                          'eager op sequence on the GPU (the fused HIP kernels cover d_k <= 128); the trunk keeps its HIP kernels')
+                          f'{embed_dim // num_content_vectors} > {bp_hip.SENSE_MAX_DK}: the sense weights and their combination '
+                          'run as the eager op sequence on the GPU (the HIP sense kernels cover d_k <= '
+                          f'{bp_hip.SENSE_MAX_DK}); the trunk keeps its HIP kernels')
 
     def project(self, encoded):
         """encoded (B,S,d) -> qk (B,S,2,k,d_k).  On the HIP path a d_k that is not a multiple of 8 (the Mini
@@ -257,7 +257,7 @@ class BackpackModel(GPTPreTrainedModel):
         self.embeddings = self.gpt2_model.embeddings   # shared with the contextualisation model
         self.contextualization_attn = ContextSelfAttn(self.num_content_vectors, config.n_embd,
                                                       use_hip=self.use_hip, **factory_kwargs)
-        # False for the few-sense ablations (d_k > 128) and off the HIP path: eager sense weights + combination
+        # False beyond d_k = 640 and off the HIP path: eager sense weights + combination
         self.fused_senses = self.contextualization_attn.fused
 
     @classmethod
@@ -292,50 +292,104 @@ class BackpackModel(GPTPreTrainedModel):
             return False
         return input_ids.numel() >= self.dedup_min_positions
 
-    def _sense_table_key(self):
+    def _sense_table_key(self, fingerprint=False):
         params = list(self.content_model.parameters())
         if any(p.is_inference() for p in params):
             return None                       # no version counter to key a cache on
-        return tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in params)
+        key = tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in params)
+        if fingerprint:
+            # `p.data.copy_()` / `p.data.mul_()` (the reference's own EMA swap, training/src/utils/ema.py:121,165) write the
+            # storage WITHOUT moving `p._version`: only the values themselves tell.  One fp32 sum per parameter, one
+            # device-to-host copy (a synchronisation: callers decide when that is affordable, `_verify_applies`).
+            with torch.no_grad():
+                sums = torch.stack([torch.sum(p.detach(), dtype=torch.float32) for p in params])
+            key = key + (tuple(sums.tolist()),)
+        return key
 
-    def sense_table(self):
+    def _verify_applies(self, input_ids):
+        """Whether this forward also checks the cached table against the parameter VALUES (`config.sense_table_verify`:
+        True / False / 'auto').  'auto' (default): forwards of at least `sense_table_verify_min_positions` positions
+        (16 384), where one ~40 us reduction and a host synchronisation are noise -- bulk evaluation, which is where
+        weights get swapped through `.data` -- and never while a stream is capturing or for small latency-bound
+        forwards (decoding), which rely on `invalidate_sense_table()` after such an update."""
+        mode = getattr(self.config, 'sense_table_verify', 'auto')
+        if mode in (False, None, 'off') or not input_ids.is_cuda or torch.cuda.is_current_stream_capturing():
+            return False
+        if mode is True or mode == 'on':
+            return True
+        return input_ids.numel() >= int(getattr(self.config, 'sense_table_verify_min_positions', 16384))
+
+    def invalidate_sense_table(self):
+        """Mark the cached whole-vocabulary sense table stale: the next eval forward (or `refresh_inference_caches()`)
+        rebuilds it IN PLACE.  Needed after parameter updates that bypass autograd's version counter -- `p.data.copy_()`,
+        `p.data.mul_()`, writes through `untyped_storage()` -- when the forward is too small for the automatic value check
+        (see `_verify_applies`).  In-place updates through the parameter itself, `load_state_dict`, `.to()` are seen
+        without it."""
+        if self._sense_table is not None:
+            self._sense_table = (None, self._sense_table[1], None)
+
+    def pin_sense_table(self, pinned=True):
+        """Keep the table's storage across `.train()` (a captured HIP graph holds its address: bp_hip.GraphedForward pins
+        it); an unpinned table is dropped when training starts."""
+        self._sense_table_pinned = bool(pinned)
+
+    def sense_table(self, verify=False):
         """(vocab rows, k, d): the content network's output for EVERY row of the word embedding, kept until a parameter of
-        the content model changes (`_version` moves on every in-place update, `data_ptr` on a reload / `.to()`), dropped
-        by `.train()`.  A refresh writes into the SAME storage, so a captured HIP graph that reads the table sees the new
-        rows (GraphedForward / generate(cg=True) call `refresh_inference_caches()` in front of a replay).  Returns None
-        when nothing can be kept (inference-mode parameters) or when the table would have to be built while a stream is
-        capturing.  1.2 GB at Backpack-Small, 4.1 GB at Mini k = 64; ~5 ms to build."""
+        the content model changes (`_version` moves on every in-place update, `data_ptr` on a reload / `.to()`; with
+        `verify` also the parameter values, which catches `.data` updates), invalidated by `.train()`.  A refresh writes
+        into the SAME storage, so a captured HIP graph that reads the table sees the new rows (bp_hip.GraphedForward
+        pins the storage and calls `refresh_inference_caches()` in front of every replay; `generate(cg=True)` captures
+        and replays inside one call, weights cannot change in between).  Returns None when nothing can be kept
+        (inference-mode parameters), when the table would have to be built while a stream is capturing, or when the
+        build runs out of memory (one warning; the forward then takes the per-position order).  1.2 GB at
+        Backpack-Small, 4.1 GB at Mini k = 64; ~5 ms to build."""
         key = self._sense_table_key()
         if key is None:
             return None
         cached = self._sense_table
         if cached is not None and cached[0] == key:
-            return cached[1]
+            if not verify:
+                return cached[1]
+            full = self._sense_table_key(fingerprint=True)
+            if cached[2] is not None and cached[2] == full:
+                return cached[1]
+            # (a table built without a fingerprint cannot vouch for the values: rebuild once, then it can)
         weight = self.embeddings.word_embeddings.weight
         if weight.is_cuda and torch.cuda.is_current_stream_capturing():
             return None
+        full = self._sense_table_key(fingerprint=True) if verify else None
         with torch.inference_mode(False), torch.no_grad():
             was_training = self.content_model.training
-            self.content_model.eval()
-            ids = torch.arange(weight.shape[0], device=weight.device).unsqueeze(0)
-            rows = self.content_model(ids)[0].transpose(0, 1)      # (V,k,d): the (1,V,k*d) block as it lies
-            self.content_model.train(was_training)
-            if cached is not None and cached[1].shape == rows.shape and cached[1].dtype == rows.dtype \
-                    and cached[1].device == rows.device:
-                cached[1].copy_(rows)
-                rows = cached[1]
-        self._sense_table = (key, rows)
+            self.content_model.eval()                 # (also the embedding module it shares with the trunk)
+            try:
+                ids = torch.arange(weight.shape[0], device=weight.device).unsqueeze(0)
+                rows = self.content_model(ids)[0].transpose(0, 1)      # (V,k,d): the (1,V,k*d) block as it lies
+                if cached is not None and cached[1].shape == rows.shape and cached[1].dtype == rows.dtype \
+                        and cached[1].device == rows.device:
+                    cached[1].copy_(rows)
+                    rows = cached[1]
+            except torch.OutOfMemoryError:
+                if not getattr(self, '_sense_table_oom_warned', False):
+                    warnings.warn('Backpack: not enough memory for the whole-vocabulary sense table; the forward runs '
+                                  'the content network per position')
+                    self._sense_table_oom_warned = True
+                return None
+            finally:
+                self.content_model.train(was_training)
+        self._sense_table = (key, rows, full)
         return rows
 
     def refresh_inference_caches(self):
         """Bring the cached sense table up to date with the weights (a no-op when it is); call in front of replaying a
-        captured graph of this model after an in-place weight update."""
+        captured graph of this model after an in-place weight update (after a `.data` update: `invalidate_sense_table()`
+        first)."""
         if self.sense_table_mode == 'cached' and self.dedup_content and self.fused_senses and not self.training:
             self.sense_table()
 
     def train(self, mode=True):
-        if mode:
-            self._sense_table = None          # training runs per position; do not hold 1-4 GB of stale rows
+        if mode and self._sense_table is not None:
+            # training runs per position; do not hold 1-4 GB of stale rows -- unless a captured graph reads this storage
+            self._sense_table = (None, self._sense_table[1], None) if getattr(self, '_sense_table_pinned', False) else None
         return super().train(mode)
 
     def _table_of_unique_tokens(self, input_ids):
@@ -355,21 +409,61 @@ class BackpackModel(GPTPreTrainedModel):
         if bp_hip.sense_mix_gather_supported(qk, rows, index.shape[1]):
             # the mix kernel reads the table rows itself: no (B,S,k,d) content tensor at all
             return bp_hip.sense_mix_gather(qk, rows, index.to(torch.int32), self.contextualization_attn.scale())
-        # shapes the gathering kernel does not take (S > 4096, a table of 4 GiB or more): torch gathers the rows
+        # shapes the gathering kernel does not take: torch gathers the rows into the (B,S,k,d) tensor the dense kernel
+        # reads -- said once per model, with the limit that was hit (bp_hip.sense_mix_gather_limits)
+        if not getattr(self, '_gather_fallback_said', False):
+            self._gather_fallback_said = True
+            warnings.warn('Backpack: the sense table is gathered by torch into a (B, S, k*d) tensor instead of inside the '
+                          'mix kernel: ' + bp_hip.sense_mix_gather_limits(qk, rows, index.shape[1]))
         content = torch.nn.functional.embedding(index, rows.reshape(rows.shape[0], -1))
         return bp_hip.sense_mix(qk, content.view(*index.shape, *rows.shape[1:]), self.contextualization_attn.scale())
+
+    # ---- the reference's order of operations (every position through the content network) at HBM-filling batches -----
+    # The contraction is per sample (reference :297-314 has no cross-sample term), so without an autograd graph the
+    # content network and the mix run over CHUNKS of samples: the (B,S,k*d) content tensor (25 MB per sample at Small,
+    # 52 GB at B = 2048) exists for one chunk at a time.  Same kernels, same per-sample arithmetic; what can differ from
+    # the whole-batch call is how the BLAS GEMMs round a row when their row count changes (as with the token tables).
+
+    def _chunked_content_applies(self, input_ids):
+        if not (self.fused_senses and input_ids.is_cuda and not torch.is_grad_enabled()) or input_ids.dim() != 2:
+            return False
+        return input_ids.shape[0] > self._content_chunk_samples(input_ids.shape[1])
+
+    def _content_chunk_samples(self, seqlen):
+        # default: 262144 positions per chunk (the content GEMMs are at their rate from ~128 k rows up; 6.4 GB of content
+        # at Small); `config.content_chunk_positions` overrides, 0 / None = never chunk
+        positions = getattr(self.config, 'content_chunk_positions', 262144)
+        if not positions:
+            return 1 << 62
+        return max(1, int(positions) // max(int(seqlen), 1))
+
+    def _mix_per_position_chunked(self, hidden, input_ids, position_ids, inference_params):
+        qk = self.contextualization_attn.project(hidden)               # (B,S,2,k,d_k): 2 d per position, whole batch
+        scale = self.contextualization_attn.scale()
+        out = torch.empty(hidden.shape, dtype=hidden.dtype, device=hidden.device)
+        step = self._content_chunk_samples(input_ids.shape[1])
+        for b0 in range(0, input_ids.shape[0], step):
+            sl = slice(b0, min(b0 + step, input_ids.shape[0]))
+            pos = position_ids[sl] if position_ids is not None and position_ids.shape[0] == input_ids.shape[0] \
+                else position_ids
+            content = self.content_model(input_ids[sl], pos, inference_params)     # (c,k,S,d) view of (c,S,k*d)
+            bp_hip.sense_mix(qk[sl], content.transpose(1, 2), scale, out=out[sl])
+            del content
+        return out
 
     def forward(self, input_ids, position_ids=None, inference_params=None):
         contextl_hidden_states = self.gpt2_model(input_ids, position_ids=position_ids,
                                                  inference_params=inference_params)
         if self._token_table_allowed(input_ids):
             if self.sense_table_mode == 'cached':
-                rows = self.sense_table()
+                rows = self.sense_table(verify=self._verify_applies(input_ids))
                 if rows is not None:
                     return self._mix_from_table(contextl_hidden_states, rows, input_ids)
             if self._dedup_applies(input_ids):
                 rows, inverse = self._table_of_unique_tokens(input_ids)
                 return self._mix_from_table(contextl_hidden_states, rows, inverse)
+        if self._chunked_content_applies(input_ids):
+            return self._mix_per_position_chunked(contextl_hidden_states, input_ids, position_ids, inference_params)
         content = self.content_model(input_ids, position_ids, inference_params)   # (B,k,S,d) view
         if self.fused_senses:
             # fused: softmax_causal(q_l k_l^T) @ C_l summed over senses, alpha never stored
@@ -431,8 +525,13 @@ class BackpackLMHeadModel(BackpackPreTrainedModel, GenerationMixin):
         if self.lm_head.bias is not None or self.lm_head.weight.dtype != hidden_states.dtype:
             raise RuntimeError(f'logits_out needs a bias-free lm_head whose weight has the activation dtype '
                                f'({self.lm_head.weight.dtype} vs {hidden_states.dtype}); call model.to(dtype) first')
-        torch.mm(hidden_states.reshape(-1, hidden_states.shape[-1]), self.lm_head.weight.t(),
-                 out=logits_out.view(-1, want[-1]))
+        x2, o2 = hidden_states.reshape(-1, hidden_states.shape[-1]), logits_out.view(-1, want[-1])
+        rows = int(getattr(self, 'lm_head_chunk_rows', 0) or 0)    # 0: one GEMM; else row chunks into the same block
+        if rows <= 0 or rows >= x2.shape[0]:
+            torch.mm(x2, self.lm_head.weight.t(), out=o2)
+        else:
+            for r0 in range(0, x2.shape[0], rows):
+                torch.mm(x2[r0:r0 + rows], self.lm_head.weight.t(), out=o2[r0:r0 + rows])
         return CausalLMOutput(logits=logits_out)
 
     def refresh_inference_caches(self):

@@ -35,6 +35,7 @@ import torch  # noqa: E402
 # MI355X peaks from /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
 PEAK_MFMA_TFLOPS = 2500.0   # dense bf16/fp16 MFMA
 PEAK_HBM_GBPS = 8000.0      # HBM3E
+MAX_SCLK_MHZ = 2400.0       # the clock the MFMA peak is quoted at
 
 WORKLOADS = {
     # name: (model, seq, dtype, default batch)  -- BASELINE.json configs[1] is the headline
@@ -79,6 +80,125 @@ class KernelClock:
         return out
 
 
+class ClockPowerSampler:
+    """Shader clock and socket power of one GPU, sampled on a side thread while a region runs (review round 5: "power
+    limited" must be checkable from the driver-run line).  Source, in order: the `amdsmi` Python binding that ships with
+    ROCm (gpu_metrics: per-XCD `current_gfxclks`, `current_socket_power`), `amdsmi_get_clock_info` / `..._power_info`,
+    sysfs (`pp_dpm_sclk` + hwmon `power1_average`).  Nothing readable -> `source: None` and null means (never a guess)."""
+
+    def __init__(self, device_index=0, period_s=0.02):
+        import threading
+        self.period = period_s
+        self.index = device_index
+        self._stop = threading.Event()
+        self._thread = None
+        self.samples = []
+        self.source = None
+        self.power_cap_w = None
+        self._read = self._pick_reader()
+
+    # -- readers: each returns (sclk_mhz or None, power_w or None) -----------------------------------------------------
+    def _pick_reader(self):
+        try:
+            import amdsmi
+            try:
+                amdsmi.amdsmi_init()
+            except Exception:
+                pass
+            handles = amdsmi.amdsmi_get_processor_handles()
+            h = handles[self.index if self.index < len(handles) else 0]
+            try:
+                cap = amdsmi.amdsmi_get_power_cap_info(h)
+                c = cap.get('power_cap')
+                if isinstance(c, (int, float)) and c > 0:
+                    self.power_cap_w = c / 1e6 if c > 1e5 else float(c)
+            except Exception:
+                pass
+
+            def num(x):
+                return float(x) if isinstance(x, (int, float)) and 0 < x < 65535 else None
+
+            def metrics():
+                m = amdsmi.amdsmi_get_gpu_metrics_info(h)
+                clks = [num(c) for c in (m.get('current_gfxclks') or [])]
+                clks = [c for c in clks if c]
+                sclk = sum(clks) / len(clks) if clks else num(m.get('current_gfxclk'))
+                pw = num(m.get('current_socket_power')) or num(m.get('average_socket_power'))
+                return sclk, pw
+
+            def infos():
+                ct = getattr(amdsmi.AmdSmiClkType, 'GFX', amdsmi.AmdSmiClkType.SYS)
+                c = amdsmi.amdsmi_get_clock_info(h, ct)
+                pw = amdsmi.amdsmi_get_power_info(h)
+                return num(c.get('clk')), (num(pw.get('current_socket_power')) or num(pw.get('average_socket_power'))
+                                           or num(pw.get('socket_power')))
+
+            for name, fn in (('amdsmi gpu_metrics (mean of current_gfxclks over the XCDs, current_socket_power)', metrics),
+                             ('amdsmi_get_clock_info(GFX).clk, amdsmi_get_power_info', infos)):
+                try:
+                    a, b = fn()
+                    if a or b:
+                        self.source = name
+                        return fn
+                except Exception:
+                    continue
+        except Exception:
+            pass
+        import glob
+        cards = sorted(glob.glob('/sys/class/drm/card[0-9]*/device/pp_dpm_sclk'))
+        if cards:
+            dev = os.path.dirname(cards[self.index if self.index < len(cards) else 0])
+            hw = sorted(glob.glob(os.path.join(dev, 'hwmon', 'hwmon*', 'power1_average'))
+                        + glob.glob(os.path.join(dev, 'hwmon', 'hwmon*', 'power1_input')))
+
+            def sysfs():
+                sclk = pw = None
+                for ln in open(os.path.join(dev, 'pp_dpm_sclk')):
+                    if '*' in ln:
+                        sclk = float(ln.split(':')[1].lower().replace('mhz', '').replace('*', '').strip())
+                if hw:
+                    pw = float(open(hw[0]).read()) / 1e6
+                return sclk, pw
+            try:
+                a, b = sysfs()
+                if a or b:
+                    self.source = 'sysfs pp_dpm_sclk (current level) + hwmon power1_average'
+                    return sysfs
+            except Exception:
+                pass
+        return None
+
+    def _loop(self):
+        while not self._stop.is_set():
+            try:
+                self.samples.append(self._read())
+            except Exception:
+                pass
+            self._stop.wait(self.period)
+
+    def start(self):
+        import threading
+        self.samples = []
+        self._stop.clear()
+        if self._read is not None:
+            self._thread = threading.Thread(target=self._loop, daemon=True)
+            self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join()
+            self._thread = None
+        clk = [a for a, _ in self.samples if a]
+        pw = [b for _, b in self.samples if b]
+        return dict(sclk_mhz_mean=round(sum(clk) / len(clk), 1) if clk else None,
+                    sclk_mhz_min=round(min(clk), 1) if clk else None, sclk_mhz_max=round(max(clk), 1) if clk else None,
+                    power_w_mean=round(sum(pw) / len(pw), 1) if pw else None,
+                    power_w_max=round(max(pw), 1) if pw else None, power_cap_w=self.power_cap_w,
+                    samples=len(self.samples), period_ms=round(self.period * 1e3, 1), source=self.source)
+
+
 def instrument(clock):
     """Bracket each HIP kernel launch with events.  The fused sense mix is split into its two
     launches (LSE pre-pass, mix) through the public lse= argument so each kernel is timed alone."""
@@ -105,6 +225,37 @@ def instrument(clock):
     bp_hip.sense_mix = mix_two_launches
     bp_hip.sense_mix_gather = gather_two_launches
     bp_hip.add_layer_norm = clock.wrap('add_layer_norm_kernel', bp_hip.add_layer_norm)
+
+
+def sustained_flash_probe(cfg, batch, seq, dtype, device, device_index, min_seconds=1.0):
+    """The trunk attention launch alone, back to back for >= `min_seconds` at the bench batch, with the clock / power
+    sampler running: the shader clock the chip SUSTAINS under this kernel (the step-level mean mixes it with the GEMMs).
+    Random q, k, v of the model's shapes (zeros would clock higher: MI355X_MICROARCH, DVFS give-back)."""
+    import bp_hip
+    h, dh = cfg.n_head, cfg.n_embd // cfg.n_head
+    try:
+        qkv = torch.randn(batch * seq, 3, h, dh, device=device, dtype=dtype)
+        o = torch.empty(batch * seq, h, dh, device=device, dtype=dtype)
+    except torch.OutOfMemoryError:
+        return None
+
+    def launch():
+        bp_hip.flash_fwd(qkv[:, 0], qkv[:, 1], qkv[:, 2], o, None, None, seq, seq, dh ** -0.5, True)
+    for _ in range(3):
+        launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); launch(); e1.record(); torch.cuda.synchronize()
+    n = max(8, int(min_seconds * 1e3 / max(e0.elapsed_time(e1), 1e-3)))
+    smi = ClockPowerSampler(device_index, period_s=0.01).start()
+    e0.record()
+    for _ in range(n):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    res = smi.stop()
+    res.update(launches=n, avg_launch_ms=round(e0.elapsed_time(e1) / n, 4))
+    return res
 
 
 def build_model(name, seq, dtype, device):
@@ -198,9 +349,13 @@ def pick_batch(model, make_ids, candidates, seq, device, logits, steps=3, hbm_li
                 fit = [c for c in candidates
                        if fixed + (per_sample_other + logits.bytes_per_sample()) * c <= hbm_limit * total_mem]
                 largest = max(fit) if fit else b
+            # what THIS batch needs: the peak minus the part of the persistent logits block (sized for the largest
+            # candidate) that this batch does not write
+            block = logits.buf.numel() * logits.buf.element_size() if logits.buf is not None else 0
+            used = peak - max(block - logits.bytes_per_sample() * b, 0)
             table.append(dict(batch=b, ms_per_step=round(dt * 1e3, 3), tokens_per_s=round(b * seq / dt, 1),
-                              peak_mem_gb=round(peak / 2**30, 1),
-                              hbm_frac=round(peak / total_mem, 3)))
+                              peak_mem_gb=round(used / 2**30, 1), hbm_frac=round(used / total_mem, 3),
+                              allocated_gb=round(peak / 2**30, 1)))
         except torch.OutOfMemoryError:
             table.append(dict(batch=b, ms_per_step=None, tokens_per_s=0.0, peak_mem_gb=None, note='out of HBM'))
         finally:
@@ -273,6 +428,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-threads', type=int, default=None)
     ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--no-clock-probe', action='store_true',
+                    help='skip the sustained run of the dominant kernel alone that measures its shader clock / power')
     ap.add_argument('--content', default=None, choices=['batch', 'cached', 'position'],
                     help="how the timed step gets its sense vectors (src/models/backpack.py, BackpackModel.sense_table_mode): "
                          "'batch' (default for eager launches) = content network once per distinct token id of the batch, the "
@@ -402,6 +559,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     clock.enabled = True
+    smi = ClockPowerSampler(local_rank).start() if rank == 0 else None   # side thread; reads the SMU's metrics table only
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -411,6 +569,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     clock.enabled = False
+    step_clocks = smi.stop() if smi is not None else None
     assert out.shape == (batch, seq, cfg.vocab_size) and bool(torch.isfinite(out[0, -1].float()).all())
 
     # The same step in the OTHER content orders (the reference's per-position order among them), timed next to the headline
@@ -424,10 +583,12 @@ def main():
             content = 'position'
 
     def time_other(mode):
-        """tokens/s of min(steps, 3) eager steps with sense_table_mode = `mode` at the headline batch (3/4 of it, repeatedly,
-        if the 25 MB per sample of per-position content tensor no longer fit)."""
+        """tokens/s of `--steps` eager steps with sense_table_mode = `mode` at the headline batch, same barriers (the
+        per-position order runs its content network and mix over chunks of samples, src/models/backpack.py, so its 25 MB
+        per sample of content tensor no longer limit the batch; should a rank still run out of HBM: 3/4 of the batch,
+        repeatedly, and the line says so in `batch_per_gpu`)."""
         model.transformer.sense_table_mode = MODES[mode]
-        n = max(1, min(args.steps, 3))
+        n = max(1, args.steps)
         b_o, result = batch, None
         while result is None:
             failed, el = 0, 0.0
@@ -583,6 +744,22 @@ def main():
                     'kernel': ln['kernel'], 'why': 'memory-bound glue around the attention path, not the path itself',
                     'bound': 'hbm', 'achieved': ln['gbps'], 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': ln['hbm_frac'],
                     'launches_per_step': ln['launches_per_step'], 'total_ms': ln['total_ms'], 'avg_launch_ms': ln['avg_ms']}
+            # clock / power: (a) over the timed region (all kernels of the step), (b) under the dominant attention
+            # launch alone, sustained.  frac_at_sustained_clock = achieved / (peak x sclk / 2400 MHz): what the launch
+            # reaches of the matrix peak at the clock the chip actually gives it.
+            if step_clocks is not None:
+                line['step_clock_power'] = step_clocks
+            if dom['kernel'] == 'flash_fwd_kernel' and not args.no_clock_probe:
+                sus = sustained_flash_probe(cfg, batch, seq, dtype, device, local_rank)
+                if sus is not None:
+                    r = line['roofline']
+                    r['sclk_mhz_mean'] = sus['sclk_mhz_mean']
+                    r['power_w_mean'] = sus['power_w_mean']
+                    r['power_cap_w'] = sus['power_cap_w']
+                    if sus['sclk_mhz_mean']:
+                        r['frac_at_sustained_clock'] = round(r['achieved'] / (PEAK_MFMA_TFLOPS * sus['sclk_mhz_mean'] / MAX_SCLK_MHZ), 4)
+                    r['sustained_probe'] = dict(sus, what='this kernel alone, back to back at the bench batch on random q, k, v; '
+                                                'sampler on a side thread')
             line['kernels'] = kernel_rows
         if sweep:
             line['batch_sweep'] = sweep

@@ -145,25 +145,28 @@ def test_mini_k64_config4_whole_model_seq1024():
 def test_mini_few_sense_ablations_whole_model_seq1024(name):
     """The few-sense ends of the reference's sense ablation at their REAL size (training/configs/experiment/owt/
     backpack-mini-flash-vecs-4.yaml: 4 senses of d_k = 160; vecs-1.yaml: one sense of d_k = 640; Mini trunk, vocab 50264,
-    S = 1024, B = 2, bf16).  Their sense width lies beyond what the fused sense kernels take (128), so the model runs the
-    sense weights and the combination as the reference's eager op sequence on the GPU and says so once
-    (`ContextSelfAttn.fused` False); the trunk's eight attention layers stay on the HIP kernels.  Against the fp32 CPU
-    oracle, 3 x rule, in every content mode the config can name (all of them then mean: per position)."""
+    S = 1024, B = 2, bf16).  Their sense width lies beyond the LDS-DMA sense kernels (128): since round 6 the wide kernels
+    of csrc/sense_wide.hip run them natively (`ContextSelfAttn.fused` True, no warning, no (B,k,S,S) tensor); the cached
+    table is gathered by torch (the gathering kernel stops at d_k = 128) and says so once.  Against the fp32 CPU oracle,
+    3 x rule, per position and from the cached table."""
     import warnings
     with warnings.catch_warnings(record=True) as caught:
         warnings.simplefilter('always')
         run = _oracle_run(name)
     t = run['hip'].transformer
-    assert not t.fused_senses and t.use_hip and any('d_k' in str(w.message) for w in caught)
+    assert t.fused_senses and t.use_hip and not any('eager op sequence' in str(w.message) for w in caught)
     assert t.gpt2_model.layers[0].mixer.use_flash_attn
-    for mode in ('off', 'cached'):
-        _assert_model_parity(run, _hidden(run, run['ids'], mode), f'{name} S=1024 [{mode}]')
-    assert t._sense_table is None                                                  # nothing to cache on this path
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter('always')
+        for mode in ('off', 'cached'):
+            _assert_model_parity(run, _hidden(run, run['ids'], mode), f'{name} S=1024 [{mode}]')
+    assert t._sense_table is not None and sum('gathered by torch' in str(w.message) for w in caught) == 1
 
 
 def test_few_sense_model_trains_on_the_hip_trunk():
-    """A training step of a few-sense model (d_k = 160: eager sense path, HIP trunk, fused LayerNorm / dense layers):
-    loss and every parameter's gradient against fp32 autograd of the eager twin (4 x rule of the config-3 test)."""
+    """A training step of a few-sense model (d_k = 160: wide sense kernels forward, alpha-rebuilding backward, HIP trunk,
+    fused LayerNorm / dense layers): loss and every parameter's gradient against fp32 autograd of the eager twin (4 x rule
+    of the config-3 test)."""
     from src.models.backpack import BackpackConfig, BackpackLMHeadModel
     import warnings
     torch.manual_seed(0)
@@ -183,7 +186,7 @@ def test_few_sense_model_trains_on_the_hip_trunk():
     eager = BackpackLMHeadModel(BackpackConfig(use_flash_attn=False, **kw)).to(DEV).float()
     hip.load_state_dict(sd)
     eager.load_state_dict(sd)
-    assert not hip.transformer.fused_senses
+    assert hip.transformer.fused_senses
     ids = torch.randint(0, 1024, (2, 256), device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
     labels = torch.roll(ids, -1, 1)
 
@@ -247,6 +250,39 @@ def test_sense_table_follows_the_weights_and_survives_graph_capture():
         assert torch.equal(fwd(ids), model(ids).logits)
         t.content_model.final_mlp.fc2.weight.mul_(0.5)
         assert torch.equal(fwd(ids), model(ids).logits)                           # GraphedForward refreshed the table
+    # periodic evaluation during training: the graph pinned the table's storage, so train() / eval() keep the address the
+    # captured kernels read; the replay refreshes it in place (advisor, round 5: the table used to be freed here)
+    model.train()
+    assert t._sense_table is not None and t._sense_table[0] is None and t._sense_table[1].data_ptr() == ptr
+    with pytest.raises(RuntimeError):
+        fwd(ids)                                                                   # captured in eval mode
+    with torch.no_grad():
+        t.content_model.final_mlp.fc2.weight.mul_(1.5)                             # "a training step"
+    model.eval()
+    with torch.no_grad():
+        assert torch.equal(fwd(ids), model(ids).logits) and t.sense_table().data_ptr() == ptr
+        # weights swapped through `.data` (the reference's EMA, training/src/utils/ema.py:121,165): `_version` does not
+        # move.  Bulk forwards check the VALUES (config.sense_table_verify = 'auto': from 16 384 positions up) ...
+        t.content_model.final_mlp.fc2.weight.data.mul_(2.0)
+        big = torch.randint(0, 1000, (64, 256), device=DEV)
+        got = t(big)
+        t.sense_table_mode = 'off'
+        want = t(big)
+        t.sense_table_mode = 'cached'
+        assert (got.float() - want.float()).abs().max().item() <= 2 ** -7 * want.float().abs().max().item()
+        assert torch.equal(fwd(ids), model(ids).logits)                            # (the rebuild was in place)
+        # ... small (latency-bound) ones rely on invalidate_sense_table()
+        t.content_model.final_mlp.fc2.weight.data.mul_(0.5)
+        stale = t(ids)
+        t.invalidate_sense_table()
+        fresh = t(ids)
+        t.sense_table_mode = 'off'
+        want = t(ids)
+        t.sense_table_mode = 'cached'
+        assert (fresh.float() - want.float()).abs().max().item() <= 2 ** -7 * want.float().abs().max().item()
+        assert (stale.float() - want.float()).abs().max().item() > 2 ** -5 * want.float().abs().max().item()
+    del fwd
+    t.pin_sense_table(False)
     model.train()
     assert t._sense_table is None
     model.eval()

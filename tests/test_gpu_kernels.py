@@ -748,3 +748,78 @@ def test_sense_mix_gather_refuses_what_it_does_not_take():
     assert not bp.sense_mix_gather_supported(qk, many_rows, 64)
     with pytest.raises(RuntimeError, match='bp_sense_mix_gather'):
         bp.sense_mix_gather(qk, many_rows, index)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [
+    # (B, S, k, d_k, d_out): wide senses, csrc/sense_wide.hip
+    (2, 1024, 4, 160, 640),    # backpack-mini-flash-vecs-4.yaml
+    (1, 1024, 1, 640, 640),    # backpack-mini-flash-vecs-1.yaml
+    (2, 300, 2, 136, 200),     # just beyond 128, ragged S, d_out not a multiple of 128
+    (3, 97, 3, 256, 72),       # one partial query tile
+    (1, 257, 1, 632, 384),     # d_k not a multiple of 16: zero columns in the last K step
+    (2, 129, 2, 132, 100),     # d_k % 8 != 0: widened to 136 by the binding; odd d_out (element-wise stores)
+])
+def test_wide_senses_lse_alpha_and_mix(shape, dtype):
+    """Senses wider than 128 (the reference's few-sense ablations: d_k = 160 / 640) through bp_sense_lse / bp_sense_alpha /
+    bp_sense_mix: each against the fp32 oracle under the kernel tests' 2 x rule, exact zeros above the diagonal of alpha,
+    rows of alpha summing to one, the fused mix equal to alpha @ C of the dumped alpha, and bp_sense_mix_weighted's hook."""
+    bp = _bp()
+    b, s, k, dk, dout = shape
+    torch.manual_seed(s + dk)
+    qk = (torch.randn(b, s, 2, k, dk) * (2.0 / dk ** 0.25)).to(dtype)
+    c = torch.randn(b, s, k, dout).to(dtype)
+    scale = dk ** -0.5
+    q32, k32 = qk[:, :, 0].float().transpose(1, 2), qk[:, :, 1].float().transpose(1, 2)      # (B,k,S,dk)
+    scores = q32 @ k32.transpose(2, 3) * scale
+    mask = torch.triu(torch.ones(s, s, dtype=torch.bool), 1)
+    lse_want = torch.logsumexp(scores.masked_fill(mask, float('-inf')), -1)
+    alpha_want = torch.softmax(scores.masked_fill(mask, float('-inf')), -1)
+    alpha_eager = R.sense_alpha_from_qk(qk)
+    want = R.sense_mix_from_qk_fp32(qk, c.transpose(1, 2))
+    eager = R.sense_mix(alpha_eager, c.transpose(1, 2))
+    g = qk.to(DEV)
+    lse = bp.sense_lse(g)[:, :, :s]
+    assert (lse.cpu() - lse_want).abs().max().item() <= 2e-3 * max(1.0, lse_want.abs().max().item())
+    alpha = bp.sense_alpha(g)
+    rel_check(alpha, alpha_want, alpha_eager, f'wide alpha {shape} {dtype}')
+    assert torch.count_nonzero(alpha[:, :, mask.to(DEV)]) == 0
+    assert (alpha.float().sum(-1) - 1).abs().max().item() < (2e-2 if dtype == torch.bfloat16 else 4e-3)
+    out = bp.sense_mix(g, c.to(DEV))
+    rel_check(out, want, eager, f'wide mix {shape} {dtype}')
+    # the hook of the intervention experiments: alpha[b, l, :, s] scaled by w[b, l, s]
+    w = torch.rand(b, k, s) * 2
+    out_w = bp.sense_mix(g, c.to(DEV), key_weight=w.to(DEV))
+    want_w = ((alpha_want * w.unsqueeze(2)) @ c.float().transpose(1, 2)).sum(1)
+    eager_w = ((alpha_eager.float() * w.unsqueeze(2)).to(dtype) @ c.transpose(1, 2)).sum(1)
+    rel_check(out_w, want_w, eager_w, f'wide weighted mix {shape} {dtype}', factor=3.0, atol=2e-3 * want_w.abs().max().item())
+    # a strided view (a slice of a bigger projection buffer, as the model hands it over)
+    big = torch.zeros(b, s, 2, k + 1, dk + 8, dtype=dtype, device=DEV)
+    big[:, :, :, :k, :dk] = g
+    assert torch.equal(bp.sense_mix(big[:, :, :, :k, :dk], c.to(DEV)), out) or dk % 8 != 0
+
+
+def test_wide_senses_backward_runs_without_opt_in():
+    """SenseMixFn at d_k = 160: forward on the wide kernels, backward through the alpha-rebuilding route (alpha is small with
+    few senses) WITHOUT `allow_eager_fallback` -- gradients against fp32 autograd of the oracle's ops."""
+    bp = _bp()
+    b, s, k, dk, d = 2, 192, 4, 160, 256
+    torch.manual_seed(0)
+    qk = (torch.randn(b, s, 2, k, dk) * 0.6).bfloat16()
+    c = torch.randn(b, s, k, d).bfloat16()
+    dout = torch.randn(b, s, d).bfloat16()
+
+    def ref(dtype):
+        q_, c_ = qk.to(dtype).requires_grad_(), c.to(dtype).requires_grad_()
+        alpha = R.sense_alpha_from_qk(q_)
+        out = torch.einsum('blts,bsld->btd', alpha, c_)
+        out.backward(dout.to(dtype))
+        return out, q_.grad, c_.grad
+
+    o32, dq32, dc32 = ref(torch.float32)
+    o16, dq16, dc16 = ref(torch.bfloat16)
+    q_, c_ = qk.to(DEV).requires_grad_(), c.to(DEV).requires_grad_()
+    out = bp.sense_mix_autograd(q_, c_)
+    out.backward(dout.to(DEV))
+    for name, got, w32, w16 in (('out', out, o32, o16), ('dqk', q_.grad, dq32, dq16), ('dC', c_.grad, dc32, dc16)):
+        rel_check(got, w32, w16, f'wide backward {name}', factor=3.0, atol=1e-3 * w32.abs().max().item())

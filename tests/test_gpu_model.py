@@ -444,3 +444,85 @@ def test_generation_on_the_hip_path_matches_the_reference_tokens():
             with torch.no_grad():
                 logits = ref(want[:, :t].to(ref.lm_head.weight.device)).logits[0, -1].float().cpu()
             assert abs(logits[seq[0, t]] - logits[want[0, t]]).item() < 0.05, (max_length, t)
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_block_with_stochastic_depth_against_the_fp32_eager_twin(fused):
+    """drop_path > 0 (reference flash_attn/modules/block.py:82-90,96-105): a sample's branch is dropped or scaled by
+    1 / (1 - p); with fused_dropout_add_ln the factor enters the fused add + LayerNorm kernel as `rowscale`.  Forward
+    and backward of the 16-bit block against an fp32 copy running the unfused op sequence with the SAME drop decisions
+    (same seed: both draw one Bernoulli number per sample and branch, in the same order)."""
+    from functools import partial
+    import torch.nn as nn
+    from flash_attn.modules.block import Block, StochasticDepth
+    from flash_attn.modules.mlp import Mlp
+    from src.models.backpack import Identity
+    dim, b, s, p_drop = 256, 12, 40, 0.4
+
+    def make(dtype, fused_ln):
+        torch.manual_seed(5)
+        blk = Block(dim, Identity, partial(Mlp, hidden_features=2 * dim, activation=partial(nn.functional.gelu, approximate='tanh')),
+                    norm_cls=partial(nn.LayerNorm, eps=1e-5), prenorm=True, resid_dropout=0.0, drop_path=p_drop,
+                    fused_dropout_add_ln=fused_ln)
+        return blk.to(DEV, dtype).train()
+
+    ref, blk = make(torch.float32, False), make(torch.bfloat16, fused)
+    assert isinstance(blk.drop_path1, StochasticDepth) and blk.drop_path2.p == p_drop
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(b, s, dim, device=DEV, generator=g)
+    res = torch.randn(b, s, dim, device=DEV, generator=g)
+    dz = torch.randn(b, s, dim, device=DEV, generator=g)
+    outs = []
+    for m, dt in ((ref, torch.float32), (blk, torch.bfloat16), (make(torch.bfloat16, False), torch.bfloat16)):
+        xi = x.to(dt).requires_grad_()
+        ri = res.clone().requires_grad_()          # the residual stream is fp32 in every variant
+        torch.manual_seed(11)
+        h, r = m(xi, ri)
+        (h.float() * dz + r.float() * dz).sum().backward()
+        outs.append([t.float() for t in (h, r, xi.grad, ri.grad, m.norm2.weight.grad, m.mlp.fc1.weight.grad)])
+    want, got, eager16 = outs
+    # the drop decisions took effect: some samples' residual is the input residual plus x exactly, others scaled
+    kept = (want[1] - res - x).flatten(1).abs().amax(1)
+    assert (kept > 1e-3).any()
+    for name, w, gt, e in zip(('hidden', 'residual', 'dx', 'dres', 'dgamma2', 'dW1'), want, got, eager16):
+        err, base = (gt - w).abs().max().item(), (e - w).abs().max().item()
+        print(f'{name}: hip {err:.3e} eager-bf16 {base:.3e}')
+        assert err <= 2 * base + 2e-3 * w.abs().max().item() + 1e-5, (name, err, base)
+    # eval: identity on the branch, no randomness
+    blk.eval()
+    with torch.no_grad():
+        a = blk(x.bfloat16(), res)[0]
+        c = blk(x.bfloat16(), res)[0]
+    assert torch.equal(a, c)
+
+
+def test_per_position_content_in_sample_chunks():
+    """sense_table = 'off' (the reference's order of operations) without an autograd graph runs the content network and
+    the mix over chunks of samples (BackpackModel._mix_per_position_chunked): the (B,S,k*d) content tensor exists for one
+    chunk at a time.  A chunk size that does not divide the batch against the whole-batch call: the mix kernel's
+    arithmetic is per sample, so rows may differ only by how the BLAS GEMMs round a row at another row count."""
+    g, sd, model = _nano(fused=True)
+    t = model.transformer
+    t.sense_table_mode = 'off'
+    ids = torch.randint(0, 96, (7, 32), device=DEV, generator=torch.Generator(device=DEV).manual_seed(0))
+    with torch.no_grad():
+        t.config.content_chunk_positions = 0                     # never chunk
+        assert not t._chunked_content_applies(ids)
+        whole = t(ids)
+        t.config.content_chunk_positions = 3 * 32                # 3 samples per chunk: 3 + 3 + 1
+        assert t._chunked_content_applies(ids) and t._content_chunk_samples(32) == 3
+        chunked = t(ids)
+        t.config.content_chunk_positions = 7 * 32                # one chunk = the whole batch: the ordinary path
+        assert not t._chunked_content_applies(ids)
+        assert torch.equal(t(ids), whole)
+    scale = whole.float().abs().max().item()
+    assert (chunked.float() - whole.float()).abs().max().item() <= 2 ** -7 * scale
+    # sample by sample the chunked call IS the model on that chunk alone
+    with torch.no_grad():
+        t.config.content_chunk_positions = 0
+        assert torch.equal(t(ids[3:6]), chunked[3:6]) or \
+            (t(ids[3:6]).float() - chunked[3:6].float()).abs().max().item() <= 2 ** -7 * scale
+    # with autograd the whole-batch path stays
+    t.config.content_chunk_positions = 32
+    with torch.enable_grad():
+        assert not t._chunked_content_applies(ids)

@@ -476,3 +476,28 @@ def test_whole_vocabulary_sense_table_is_the_content_network_row_by_row_and_foll
         assert torch.equal(model(ids).logits - logits, model(ids).logits - logits)   # (CPU forward unaffected; finite)
     with pytest.raises(AssertionError):
         BackpackLMHeadModel(nano_config(sense_table='sometimes'))
+    # updates through `.data` do not move `_version` (the reference's EMA swap, training/src/utils/ema.py:121,165): the
+    # version key alone keeps serving the old rows; the value check (`verify`, automatic for bulk forwards on the GPU)
+    # and `invalidate_sense_table()` both catch it, and both rebuild in the SAME storage
+    table = t.sense_table()
+    ptr, before = table.data_ptr(), table.clone()
+    t.content_model.final_mlp.fc2.bias.data.add_(2.0)
+    assert torch.equal(t.sense_table(), before)                        # stale, by construction of the version key
+    fresh = t.sense_table(verify=True)
+    assert fresh.data_ptr() == ptr and torch.allclose(fresh, before + 2.0, atol=1e-5)
+    assert t.sense_table(verify=True) is fresh                         # values unchanged: kept
+    t.content_model.final_mlp.fc2.bias.data.add_(1.0)
+    t.invalidate_sense_table()
+    assert torch.allclose(t.sense_table(), before + 3.0, atol=1e-5) and t.sense_table().data_ptr() == ptr
+    # a pinned table (a captured graph holds its address) survives .train() as storage and is refilled in place
+    t.pin_sense_table()
+    model.train()
+    assert t._sense_table is not None and t._sense_table[0] is None
+    model.eval()
+    assert t.sense_table().data_ptr() == ptr
+    t.pin_sense_table(False)
+    model.train()
+    assert t._sense_table is None
+    model.eval()
+    # 'auto' verification: never for CPU tensors, on the GPU from `sense_table_verify_min_positions` positions up
+    assert not t._verify_applies(ids)
