@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('BP_HIP_LIB') or os.path.join(_HERE, 'libbackpack_hip.so')  # env: A/B builds only
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _lib = None
 
@@ -52,6 +52,7 @@ _i32, _i64, _f32, _ptr = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_
 SIGNATURES = {
     'bp_strerror': (ctypes.c_char_p, [_i32]),
     'bp_abi_version': (_i32, []),
+    'bp_build_flags': (_i32, []),
     'bp_flash_fwd': (_i32, [_ptr] * 7 + [_i32] * 5 + [_i64] * 9 + [_f32, _i32, _i32, _ptr]),
     'bp_flash_fwd_dropout': (_i32, [_ptr] * 7 + [_i32] * 5 + [_i64] * 9 + [_f32, _i32, _i32, _f32, _ptr, _ptr]),
     'bp_flash_bwd_ws_floats': (_i64, [_i32, _i32, _i64]),
@@ -99,6 +100,14 @@ def lib():
             fn.argtypes = argtypes
         if handle.bp_abi_version() != ABI_VERSION:
             raise RuntimeError('libbackpack_hip.so ABI version mismatch; rebuild it')
+        flags = handle.bp_build_flags()
+        if flags & 3:
+            # timing builds (-DBP_FWD_WHATIF / -DBP_BWD_WHATIF) delete work on purpose: never as the default library
+            if not os.environ.get('BP_HIP_LIB'):
+                raise RuntimeError(f'{LIB_PATH} is a what-if TIMING build (bp_build_flags() = {flags}): its results are '
+                                   'garbage; rebuild without -DBP_FWD_WHATIF / -DBP_BWD_WHATIF')
+            import warnings
+            warnings.warn(f'bp_hip: {LIB_PATH} is a what-if timing build (flags {flags}): results are garbage on purpose')
         _lib = handle
     return _lib
 

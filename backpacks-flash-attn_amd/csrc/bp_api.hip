@@ -91,6 +91,20 @@ const char *bp_strerror(int code) {
 
 int bp_abi_version(void) { return BP_ABI_VERSION; }
 
+int bp_build_flags(void) {
+    int flags = 0;
+#ifdef BP_FWD_WHATIF
+    flags |= 1;
+#endif
+#if defined(BP_BWD_WHATIF) && BP_BWD_WHATIF != 0
+    flags |= 2;
+#endif
+#ifdef BP_DEV_BUILD
+    flags |= 4;
+#endif
+    return flags;
+}
+
 int bp_flash_fwd(const void *q, const void *k, const void *v, void *out, float *softmax_lse,
                  const int32_t *cu_seqlens_q, const int32_t *cu_seqlens_k,
                  int batch, int nheads, int head_dim, int max_seqlen_q, int max_seqlen_k,

@@ -63,6 +63,8 @@ namespace {
 // s_barrier (racy), 16 no epilogue stores, 32 no softmax VALU at all.  0 in the shipped library: every test below folds away.
 #ifndef BP_BWD_WHATIF
 #define BP_BWD_WHATIF 0
+#elif BP_BWD_WHATIF != 0
+#warning "BP_BWD_WHATIF: timing build of flash_bwd.hip -- gradients are garbage (bp_build_flags() reports it, bp_hip refuses it as the default library)"
 #endif
 constexpr int kWhatIf = BP_BWD_WHATIF;
 

@@ -30,10 +30,11 @@
 #ifndef BP_FWD_STREAM
 #define BP_FWD_STREAM 1
 #endif
-#ifndef BP_FWD_PERSIST
-#define BP_FWD_PERSIST 0
+// epilogue: O as 16-byte column groups (one v_permlane32_swap per dword pairs the half-waves' 8-byte pieces) instead of
+// 8-byte stores; measured in profiles/r06_c_ab_flash_wide_store.jsonl
+#ifndef BP_FWD_WIDE_STORE
+#define BP_FWD_WIDE_STORE 0
 #endif
-#include <algorithm>
 #include "bp_common.h"
 #include "bp_dma.h"
 #include "bp_kernels.h"
@@ -46,18 +47,6 @@
 #endif
 
 namespace bp {
-
-// Timing builds only (-DBP_FWD_WHATIF=<bits>, scripts/probes/flash_fwd_whatif): 1 = no MFMAs (operands still read), 2 = no
-// softmax VALU.  Results are garbage on purpose; the library says so when it is built (and bp_abi_build_flags() reports it).
-#ifdef BP_FWD_WHATIF
-#warning "BP_FWD_WHATIF: timing build of flash_fwd_dma.hip -- results are garbage"
-template <class ET> BP_DEV f32x16 fwd_mfma(u32x4 a, u32x4 b, f32x16 c) {
-    if (BP_FWD_WHATIF & 1) { asm volatile("" ::"v"(a), "v"(b)); return c; }
-    return Elem<ET>::mfma(a, b, c);
-}
-#else
-template <class ET> BP_DEV f32x16 fwd_mfma(u32x4 a, u32x4 b, f32x16 c) { return Elem<ET>::mfma(a, b, c); }
-#endif
 
 // Development builds only (-DBP_FWD_PROFILE, scripts/probes/flash_fwd_phases): every wave adds up s_memtime deltas per
 // phase of a pass; never in the shipped library.
@@ -287,7 +276,7 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
 #pragma unroll
         for (int s = 0; s < KD; ++s) {
             const u32x4 a = lds_read_16B(kbuf, k_read_off[s] + kk * 32 * C::KROW);
-            s_ = fwd_mfma<ET>(a, qf[s], s_);
+            s_ = E::mfma(a, qf[s], s_);
         }
         return s_;
     };
@@ -321,10 +310,6 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int r = ks * 8 + 2 * i;
-#if defined(BP_FWD_WHATIF) && (BP_FWD_WHATIF & 2)
-                    pf[kk][ks][i] = as_u32(st[kk][r]) ^ as_u32(st[kk][r + 1]);
-                    continue;
-#endif
                     const float x0 = fast_exp2(fmaf(st[kk][r], c2, -mc));
                     const float x1 = fast_exp2(fmaf(st[kk][r + 1], c2, -mc));
                     const uint32_t w = E::pack2(x0, x1);
@@ -346,7 +331,7 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
                     const u32x2 lo = lds_read_tr16_8B(vbuf, v_read_off[n] + rows);
                     const u32x2 hi = lds_read_tr16_8B(vbuf, v_read_off[n] + rows + 8 * C::VROW);
                     const u32x4 a = {lo[0], lo[1], hi[0], hi[1]};
-                    acc[n] = fwd_mfma<ET>(a, pf[kk][ks], acc[n]);
+                    acc[n] = E::mfma(a, pf[kk][ks], acc[n]);
                 }
             }
         }
@@ -375,7 +360,7 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
                     const u32x2 lo = lds_read_tr16_8B(vbuf, v_read_off[n] + rows);
                     const u32x2 hi = lds_read_tr16_8B(vbuf, v_read_off[n] + rows + 8 * C::VROW);
                     const u32x4 a = {lo[0], lo[1], hi[0], hi[1]};
-                    acc[n] = fwd_mfma<ET>(a, pf, acc[n]);
+                    acc[n] = E::mfma(a, pf, acc[n]);
                 }
             }
         }
@@ -450,7 +435,7 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
                 for (int r = 0; r < 16; ++r) zero[r] = 0.f;
                 mfma_stream<2 * KD>(
                     [&](int i) { return lds_read_16B(kbuf, k_read_off[i >> 1] + (i & 1) * 32 * C::KROW); },
-                    [&](int i, const u32x4 &a) { st[i & 1] = fwd_mfma<ET>(a, qf[i >> 1], i < 2 ? zero : st[i & 1]); });
+                    [&](int i, const u32x4 &a) { st[i & 1] = E::mfma(a, qf[i >> 1], i < 2 ? zero : st[i & 1]); });
             }
 #else
             st[0] = scores(kbuf, 0);
@@ -536,6 +521,29 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
         }
         if (HAS_V) {
             uint16_t *og = reinterpret_cast<uint16_t *>(p.o) + o_off + (int64_t)my_q * p.o_rs + (int64_t)head * p.o_hs;
+#if BP_FWD_WIDE_STORE
+            // 16-byte column groups: a lane holds columns 8g + 4hh .. +3 of its row for every g; one v_permlane32_swap per
+            // dword pairs groups (g, g + 1) across the half-waves -- the lower half-wave then owns columns 8g .. 8g+7, the
+            // upper one 8(g+1) .. 8(g+1)+7 -- and the epilogue issues half the store instructions for the same bytes
+            // (the store tail of a row-per-lane epilogue is bound by store ISSUE, not bandwidth: cdna_hip_programming T21)
+#pragma unroll
+            for (int n = 0; n < NV; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    const uint32_t a0 = E::pack2(acc[n][4 * g + 0] * inv, acc[n][4 * g + 1] * inv);
+                    const uint32_t a1 = E::pack2(acc[n][4 * g + 2] * inv, acc[n][4 * g + 3] * inv);
+                    const uint32_t b0 = E::pack2(acc[n][4 * g + 4] * inv, acc[n][4 * g + 5] * inv);
+                    const uint32_t b1 = E::pack2(acc[n][4 * g + 6] * inv, acc[n][4 * g + 7] * inv);
+                    auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                    const uint32_t x0 = r0[0], y0 = r0[1], x1 = r1[0], y1 = r1[1];
+                    const int d0 = n * 32 + 8 * g + 8 * hh;
+                    if (d0 < p.d) {
+                        const u32x4 w = {x0, x1, y0, y1};
+                        *reinterpret_cast<u32x4 *>(og + d0) = w;
+                    }
+                }
+#else
 #pragma unroll
             for (int n = 0; n < NV; ++n)
 #pragma unroll
@@ -547,539 +555,12 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
                         *reinterpret_cast<u32x2 *>(og + d0) = w;
                     }
                 }
+#endif
         }
     }
 #ifdef BP_FWD_PROFILE
     flush(__builtin_readcyclecounter());
 #endif
-}
-
-// =====================================================================================================================
-// Persistent form (round 6).  The launch above gives every (sample, head, tile pair) its own workgroup: per pass a wave
-// waits out TWO exposed memory round trips (its Q fragments, then key tile 0) before the first MFMA, its epilogue stores sit
-// in front of the next pass's first counted wait, and a workgroup's lifetime has a launch on either side.  Here a
-// workgroup is resident for the whole launch and walks the pass list of its XCD (the same list, in the same order, as
-// the dispatcher would have handed it out: slot c, c + G, c + 2G ... of XCD-local blocks -- static, no tickets, no
-// workspace, deterministic), and the pass seam carries no exposed round trip:
-//   * during the LAST ring step of a pass the free ring slot receives key tile 0 of the NEXT pass (the slot alternation
-//     simply continues across the seam),
-//   * the next pass's Q fragments are requested into fresh registers as soon as the last S^T has consumed the old ones
-//     (the last tile of a causal pass is an exact tile: no retry can need them again) and are waited for BEFORE the epilogue
-//     stores are issued, so no wait of the next pass ever has a store in front of it; its first ring step needs only the
-//     barrier,
-//   * the epilogue stores whole 16-byte column groups (one v_permlane32_swap per dword pairs the half-waves' 8-byte
-//     pieces: half the store instructions of the same bytes).
-// Tile bodies, reference-point bookkeeping and every result bit are those of flash_fwd_tile.
-struct FwdPass {   // one 128-query tile of one (sample, head); wave-uniform
-    int valid, bh, qt, batch, head, seq_q, seq_k, nkb;
-    int64_t q_off, k_off, v_off, o_off;
-};
-
-BP_DEV const uint16_t *uniform_ptr(const uint16_t *ptr) {
-    const uint64_t v = (uint64_t)ptr;
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-    return (const uint16_t *)(((uint64_t)hi << 32) | lo);
-}
-
-// The pass seam is cold code that needs half of FlashParams (pointers, strides, sequence offsets).  Read through the
-// by-value kernel argument those fields are loop-invariant SGPRs, live across the whole tile loop, and hipcc spills a
-// hundred of them to VGPR lanes -- v_readlane / v_writelane in every ring step.  So the seam re-reads what it needs from
-// the kernarg segment (scalar loads, scalar cache) through a pointer the optimiser cannot see through: nothing of it is
-// hoisted out of the loop, nothing stays live in between.
-typedef const FlashParams __attribute__((address_space(4))) *fwd_params_t;
-BP_DEV fwd_params_t fwd_kernarg() {
-    fwd_params_t kp = (fwd_params_t)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(kp));
-    return kp;
-}
-
-// Cursor over the passes of this workgroup: XCD-local slot `js` (advanced by G = resident workgroups per XCD) and the pass
-// inside the slot's tile pair.  Returns the next pass that has rows; valid = 0 when the list is exhausted.
-template <class C>
-BP_DEV FwdPass fwd_next_pass(int &js, int &pass) {
-    const fwd_params_t kp = fwd_kernarg();
-    const int n_qtiles = (kp->max_sq + C::BM - 1) / C::BM;
-    const bool pair = kp->pair && n_qtiles > 1;
-    const int per_group = pair ? (n_qtiles + 1) / 2 : n_qtiles;
-    const int xcd = blockIdx.x & 7, G = gridDim.x >> 3;
-    const int ngroups = kp->b * kp->h, heads = kp->h;
-    FwdPass d;
-    d.valid = 0;
-    for (;;) {
-        if (pass < 0) {
-            pass = 0;
-        } else {
-            const int item = js % per_group;
-            if (pass == 0 && pair && item != n_qtiles - 1 - item) pass = 1;
-            else { js += G; pass = 0; }
-        }
-        const int group = (js / per_group) * 8 + xcd;
-        if (group >= ngroups) return d;
-        const int item = js - (js / per_group) * per_group;
-        d.bh = group;
-        d.qt = pass ? item : n_qtiles - 1 - item;
-        d.batch = group / heads;
-        d.head = group - d.batch * heads;
-        if (kp->cu_q != nullptr) {
-            // (read through the constant address space: scalar loads -- a vector load here would put a vmcnt(0) wait,
-            // i.e. the whole DMA queue, into the last ring step of every pass; the offsets are not written during the launch)
-            typedef const int __attribute__((address_space(4))) *cu_t;
-            const cu_t cq = (cu_t)(uintptr_t)kp->cu_q, ck = (cu_t)(uintptr_t)kp->cu_k;
-            const int a = cq[d.batch], b = cq[d.batch + 1];
-            const int c = ck[d.batch], e = ck[d.batch + 1];
-            d.seq_q = b - a; d.seq_k = e - c;
-            d.q_off = a * kp->q_rs; d.o_off = a * kp->o_rs; d.k_off = c * kp->k_rs; d.v_off = c * kp->v_rs;
-        } else {
-            d.seq_q = kp->max_sq; d.seq_k = kp->max_sk;
-            d.q_off = d.batch * kp->q_bs; d.o_off = d.batch * kp->o_bs; d.k_off = d.batch * kp->k_bs; d.v_off = d.batch * kp->v_bs;
-        }
-        if (d.qt * C::BM >= d.seq_q) continue;   // this tile has no rows (ragged batch): nothing to write
-        int k_end = d.seq_k;
-        if (kp->causal) k_end = min(d.seq_k, d.qt * C::BM + C::BM);
-        d.nkb = (k_end + C::BN - 1) / C::BN;
-        d.valid = 1;
-        return d;
-    }
-}
-
-template <class ET, int KD, int NV, bool HAS_V, bool FULLD, bool DROP>
-BP_DEV void flash_fwd_persistent(const FlashParams p, char *smem, const uint32_t lds0) {
-    using C = FlashDmaCfg<KD, NV, HAS_V>;
-    using E = Elem<ET>;
-    static_assert(C::NWAVE == 4, "the persistent form is written for four-wave workgroups");
-    constexpr float kLimit = ProbLimit<ET>::value;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31;
-    const int hh = lane >> 5;
-    const float c2 = p.scale_log2e;
-
-    // ---- the pass list of this workgroup ------------------------------------------------------------------------------
-    int js = blockIdx.x >> 3, pass_ix = -1;
-    FwdPass cur = fwd_next_pass<C>(js, pass_ix);
-    if (!cur.valid) return;
-
-    // K pad slots are never written by the DMA and meet zero Q columns in the MFMA: finite values once, for the whole launch
-    if (!FULLD) {
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        for (int off = tid * 16; off < C::NSTAGE * C::STAGE; off += C::NT * 16) lds_write_16B(smem, off, z);
-        __syncthreads();
-    }
-
-    // ---- per-lane DMA source descriptors (as flash_fwd_tile) ----------------------------------------------------------
-    int k_col[C::K_DMA];
-    uint32_t k_voff[C::K_DMA];
-#pragma unroll
-    for (int j = 0; j < C::K_DMA; ++j) {
-        const int g = (wave * C::K_DMA + j) * 64 + lane;
-        const int row = g / C::KSLOTS;
-        k_col[j] = (C::ODD ? g - row * C::KSLOTS : (g - row * C::KSLOTS) ^ k_swz<C::KROW>(row)) * 8;
-        k_voff[j] = (uint32_t)(row * p.k_rs + k_col[j]) * 2u;
-    }
-    int v_col[HAS_V ? C::V_DMA : 1];
-    uint32_t v_voff[HAS_V ? C::V_DMA : 1];
-    if (HAS_V) {
-#pragma unroll
-        for (int j = 0; j < C::V_DMA; ++j) {
-            const int c = (wave * C::V_DMA + j) * 64 + lane;
-            const int row = c / C::VCH, stored = c - row * C::VCH;
-            int c64 = stored >> 2;
-            if (NV == 2) c64 ^= (row >> 1) & 1;
-            if (NV == 4) c64 ^= row & 3;
-            v_col[j] = ((c64 << 2) | (stored & 3)) * 8;
-            v_voff[j] = (uint32_t)(row * p.v_rs + v_col[j]) * 2u;
-        }
-    }
-    const int64_t k_tile_stride = (int64_t)C::BN * p.k_rs, v_tile_stride = (int64_t)C::BN * p.v_rs;
-
-    // One K (+ V) tile into ring slot `slot`.  `last_row` >= 0: the sequence's partial last tile, rows clamped to it.
-    auto issue = [&](const uint16_t *ktile, const uint16_t *vtile, const int last_row, const int slot) {
-        const uint32_t stage = __builtin_amdgcn_readfirstlane(lds0 + slot * C::STAGE);
-        ktile = uniform_ptr(ktile);
-        if (HAS_V) vtile = uniform_ptr(vtile);
-        if (__builtin_expect(last_row >= 0, 0)) {
-#pragma unroll
-            for (int j = 0; j < C::K_DMA; ++j) {
-                const int row = ((wave * C::K_DMA + j) * 64 + lane_id_now()) / C::KSLOTS;
-                const uint32_t back = (uint32_t)(max(row - last_row, 0) * p.k_rs) * 2u;
-                if (wave * C::K_DMA + j < C::K_PIECES && (FULLD || k_col[j] < p.d))
-                    dma16_s(ktile, k_voff[j] - back, __builtin_amdgcn_readfirstlane(stage + (wave * C::K_DMA + j) * 1024));
-            }
-            if (HAS_V) {
-#pragma unroll
-                for (int j = 0; j < C::V_DMA; ++j) {
-                    const int row = ((wave * C::V_DMA + j) * 64 + lane_id_now()) / C::VCH;
-                    const uint32_t back = (uint32_t)(max(row - last_row, 0) * p.v_rs) * 2u;
-                    if (FULLD || v_col[j] < p.d)
-                        dma16_s(vtile, v_voff[j] - back,
-                                __builtin_amdgcn_readfirstlane(stage + C::KTILE + (wave * C::V_DMA + j) * 1024));
-                }
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < C::K_DMA; ++j)
-                if (wave * C::K_DMA + j < C::K_PIECES && (FULLD || k_col[j] < p.d))
-                    dma16_s(ktile, k_voff[j], __builtin_amdgcn_readfirstlane(stage + (wave * C::K_DMA + j) * 1024));
-            if (HAS_V) {
-#pragma unroll
-                for (int j = 0; j < C::V_DMA; ++j)
-                    if (FULLD || v_col[j] < p.d)
-                        dma16_s(vtile, v_voff[j],
-                                __builtin_amdgcn_readfirstlane(stage + C::KTILE + (wave * C::V_DMA + j) * 1024));
-            }
-        }
-    };
-    // partial-tile row limit of key tile kb of a sequence of seq_k keys, or -1
-    auto partial_rows = [&](const int seq_k, const int kb) {
-        return ((seq_k % C::BN) != 0 && kb == seq_k / C::BN) ? seq_k - 1 - (seq_k / C::BN) * C::BN : -1;
-    };
-
-    int k_read_off[KD];
-#pragma unroll
-    for (int s = 0; s < KD; ++s)
-        k_read_off[s] = l31 * C::KROW + (C::ODD ? 2 * s + hh : (2 * s + hh) ^ k_swz<C::KROW>(l31)) * 16;
-    int v_read_off[HAS_V ? NV : 1];
-    if (HAS_V) {
-        const int v_row_lane = 4 * hh + ((lane & 15) >> 2);
-        const int v_ch_lane = ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1);
-#pragma unroll
-        for (int n = 0; n < NV; ++n) v_read_off[n] = v_lds_off<NV>(v_row_lane, n * 4 + v_ch_lane) + (lane & 1) * 8;
-    }
-
-    // ---- state of the pass in flight ----------------------------------------------------------------------------------
-    const uint16_t *kt = nullptr, *vt = nullptr;   // tile of the NEXT issue
-    uint16_t *o_base = nullptr;                    // row 0 of this (sample, head) in O
-    float *lse_base = nullptr;
-    int kb = 0, nkb = 0, seq_q = 0, seq_k = 0, q0 = 0, my_q = 0, my_nkb = 0, my_clean_end = 0;
-    bool wave_has_rows = false;
-    DropoutStream rng = {0u, 0u};
-    u32x4 qf[KD];
-    f32x16 acc[HAS_V ? NV : 1];
-    float m_run = -INFINITY, mc = 0.f, l_run = 0.f;
-
-    auto q_row = [&](const FwdPass &d) {   // my lane's query row of pass d
-        const fwd_params_t kp = fwd_kernarg();
-        const int row = min(d.qt * C::BM + wave * 32 + l31, d.seq_q - 1);
-        return reinterpret_cast<const uint16_t *>(kp->q) + d.q_off + (int64_t)d.head * kp->q_hs + (int64_t)row * kp->q_rs;
-    };
-    // Q fragments of pass d, requested INTO qf (the caller knows the current ones are dead); wait = settle_q()
-    auto q_request = [&](const FwdPass &d) {
-        const uint16_t *row = q_row(d);
-#pragma unroll
-        for (int s = 0; s < KD; ++s) {
-            const int col = 16 * s + 8 * hh;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (FULLD || col < p.d) v = ld_global_16B(row + col);
-            qf[s] = v;
-        }
-    };
-    // Pull my rows of pass d's Q into the L2 without a destination register: one 4-byte LDS-DMA per 128-byte line and lane
-    // pair (lane l31 -> row, half-wave -> 64-byte half) into a 256-byte scratch area per wave behind the ring.  Counted by
-    // the ring's own waits like every other DMA piece.
-    auto q_touch = [&](const FwdPass &d) {
-        const uint16_t *row = q_row(d);
-#pragma unroll
-        for (int c = 0; c < KD * 16; c += 64)
-            if (FULLD || c + 32 * hh < p.d) dma4(row + c + 32 * hh, lds0 + C::NSTAGE * C::STAGE + wave * 256);
-    };
-    auto settle_q = [&]() {
-#pragma unroll
-        for (int s = 0; s < KD; ++s) settle(qf[s]);
-    };
-    // everything of a pass but its Q fragments and its first key tile
-    auto begin_pass = [&](const FwdPass &d) {
-        const fwd_params_t kp = fwd_kernarg();
-        seq_q = d.seq_q; seq_k = d.seq_k; nkb = d.nkb; kb = 0;
-        // (tile 1 is the next one to issue: tile 0 goes out at the seam / in cold_start)
-        kt = reinterpret_cast<const uint16_t *>(kp->k) + d.k_off + (int64_t)d.head * kp->k_hs + k_tile_stride;
-        vt = HAS_V ? reinterpret_cast<const uint16_t *>(kp->v) + d.v_off + (int64_t)d.head * kp->v_hs + v_tile_stride : nullptr;
-        o_base = HAS_V ? reinterpret_cast<uint16_t *>(kp->o) + d.o_off + (int64_t)d.head * kp->o_hs : nullptr;
-        lse_base = kp->lse != nullptr ? kp->lse + ((int64_t)d.batch * kp->h + d.head) * kp->lse_stride : nullptr;
-        q0 = d.qt * C::BM + wave * 32;
-        my_q = q0 + l31;
-        wave_has_rows = q0 < seq_q;
-        my_nkb = !wave_has_rows ? 0 : p.causal ? min(nkb, (q0 + 31) / C::BN + 1) : nkb;
-        my_clean_end = p.causal ? min(seq_k / C::BN, (q0 + 1) / C::BN) : seq_k / C::BN;
-        if (DROP) rng = dropout_stream(p.rng_state, (uint32_t)d.bh);
-#pragma unroll
-        for (int n = 0; n < (HAS_V ? NV : 1); ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-        m_run = -INFINITY; mc = 0.f; l_run = 0.f;
-    };
-
-    // ---- tile bodies (flash_fwd_tile's, on the state above) -----------------------------------------------------------
-    auto exponentiate = [&](f32x16 (&st)[2]) {
-        float rs0 = 0.f, rs1 = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const float x0 = fast_exp2(fmaf(st[kk][r], c2, -mc));
-                const float x1 = fast_exp2(fmaf(st[kk][r + 1], c2, -mc));
-                st[kk][r] = x0;
-                st[kk][r + 1] = x1;
-                rs0 += x0;
-                rs1 += x1;
-            }
-        return rs0 + rs1;
-    };
-    constexpr bool PACKED_SUM = HAS_V && !DROP;
-    u32x4 pf[2][2];
-    auto exponentiate_packed = [&](f32x16 (&st)[2]) {
-        float rs0 = 0.f, rs1 = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = ks * 8 + 2 * i;
-#if defined(BP_FWD_WHATIF) && (BP_FWD_WHATIF & 2)
-                    pf[kk][ks][i] = as_u32(st[kk][r]) ^ as_u32(st[kk][r + 1]);
-                    continue;
-#endif
-                    const float x0 = fast_exp2(fmaf(st[kk][r], c2, -mc));
-                    const float x1 = fast_exp2(fmaf(st[kk][r + 1], c2, -mc));
-                    const uint32_t w = E::pack2(x0, x1);
-                    pf[kk][ks][i] = w;
-                    if (i & 1) rs1 = E::add_pair(w, rs1);
-                    else rs0 = E::add_pair(w, rs0);
-                }
-        return rs0 + rs1;
-    };
-    auto accumulate_packed = [&](const char *vbuf, bool skip_hi) {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            if (kk == 1 && skip_hi) continue;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int rows = (kk * 32 + ks * 16) * C::VROW;
-#pragma unroll
-                for (int n = 0; n < NV; ++n) {
-                    const u32x2 lo = lds_read_tr16_8B(vbuf, v_read_off[n] + rows);
-                    const u32x2 hi = lds_read_tr16_8B(vbuf, v_read_off[n] + rows + 8 * C::VROW);
-                    const u32x4 a = {lo[0], lo[1], hi[0], hi[1]};
-                    acc[n] = fwd_mfma<ET>(a, pf[kk][ks], acc[n]);
-                }
-            }
-        }
-    };
-    auto accumulate = [&](int kbi, const char *vbuf, f32x16 (&st)[2], bool skip_hi) {
-        if (!HAS_V) return;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            if (kk == 1 && skip_hi) continue;
-            if (DROP) {
-                const uint32_t keep = dropout_keep_rowlane(rng, p.drop_thr, (uint32_t)my_q,
-                                                           (uint32_t)(kbi * C::BN + kk * 32), hh);
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (!((keep >> r) & 1u)) st[kk][r] = 0.f;
-            }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                u32x4 pw;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) pw[i] = E::pack2(st[kk][ks * 8 + 2 * i], st[kk][ks * 8 + 2 * i + 1]);
-                const int rows = (kk * 32 + ks * 16) * C::VROW;
-#pragma unroll
-                for (int n = 0; n < NV; ++n) {
-                    const u32x2 lo = lds_read_tr16_8B(vbuf, v_read_off[n] + rows);
-                    const u32x2 hi = lds_read_tr16_8B(vbuf, v_read_off[n] + rows + 8 * C::VROW);
-                    const u32x4 a = {lo[0], lo[1], hi[0], hi[1]};
-                    acc[n] = fwd_mfma<ET>(a, pw, acc[n]);
-                }
-            }
-        }
-    };
-    auto online_max_step = [&](int kbi, f32x16 (&st)[2], bool moves) {
-        int last = seq_k - 1;
-        if (p.causal) last = min(last, my_q);
-        int lim = last - kbi * C::BN - 4 * hh;
-        asm volatile("" : "+v"(lim));
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (kk * 32 + (r & 3) + 8 * (r >> 2) > lim) st[kk][r] = -INFINITY;
-        float mxa = st[0][0], mxb = st[0][8], mxc = st[1][0], mxd = st[1][8];
-#pragma unroll
-        for (int r = 1; r < 8; ++r) {
-            mxa = fmaxf(mxa, st[0][r]);
-            mxb = fmaxf(mxb, st[0][8 + r]);
-            mxc = fmaxf(mxc, st[1][r]);
-            mxd = fmaxf(mxd, st[1][8 + r]);
-        }
-        const float mt = xhalf_max(fmaxf(fmaxf(mxa, mxb), fmaxf(mxc, mxd)));
-        const float m_new = moves ? fmaxf(mt, m_run) : m_run;
-        const float mc_new = !moves ? mc : (m_new == -INFINITY) ? 0.f : m_new * c2;
-        const float alpha = moves ? fast_exp2(m_run * c2 - mc_new) : 1.f;
-        l_run *= alpha;
-        if (HAS_V) {
-#pragma unroll
-            for (int n = 0; n < NV; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[n][r] *= alpha;
-        }
-        m_run = m_new;
-        mc = mc_new;
-    };
-    // One key tile (see flash_fwd_tile).
-    auto tile = [&](int kbi, const char *kbuf, const char *vbuf, bool exact) {
-        f32x16 st[2];
-        float rs;
-        bool moves = true;
-        for (;;) {
-            {
-                f32x16 zero;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-                mfma_stream<2 * KD>(
-                    [&](int i) { return lds_read_16B(kbuf, k_read_off[i >> 1] + (i & 1) * 32 * C::KROW); },
-                    [&](int i, const u32x4 &a) { st[i & 1] = fwd_mfma<ET>(a, qf[i >> 1], i < 2 ? zero : st[i & 1]); });
-            }
-            if (__builtin_expect(exact, 0)) online_max_step(kbi, st, moves);
-            rs = PACKED_SUM ? exponentiate_packed(st) : exponentiate(st);
-            if (__builtin_expect(exact || __all(rs <= kLimit), 1)) break;
-            moves = xhalf_max(rs <= kLimit ? 0.f : 1.f) != 0.f;
-            exact = true;
-        }
-        l_run += rs;
-        const bool skip_hi = p.causal && (kbi * C::BN + 32 > q0 + 31);
-        if (PACKED_SUM) accumulate_packed(vbuf, skip_hi);
-        else accumulate(kbi, vbuf, st, skip_hi);
-    };
-
-    // ---- epilogue of the pass in flight: normalise, LSE, O as 16-byte column groups ------------------------------------
-    auto finish_pass = [&](const bool settle_next) {
-        const float l_tot = xhalf_sum(l_run);
-        float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
-        if (DROP) inv *= p.drop_scale;
-        uint32_t ow[HAS_V ? NV : 1][8];
-        if (HAS_V) {
-#pragma unroll
-            for (int n = 0; n < NV; ++n)
-#pragma unroll
-                for (int g = 0; g < 4; g += 2) {
-                    // this lane: columns n*32 + 8g + 4hh .. +3 (a) and n*32 + 8(g+1) + 4hh .. +3 (b) of its row; after the
-                    // swaps the lower half-wave holds columns 8g .. 8g+7, the upper one 8(g+1) .. 8(g+1)+7
-                    uint32_t a0 = E::pack2(acc[n][4 * g + 0] * inv, acc[n][4 * g + 1] * inv);
-                    uint32_t a1 = E::pack2(acc[n][4 * g + 2] * inv, acc[n][4 * g + 3] * inv);
-                    uint32_t b0 = E::pack2(acc[n][4 * g + 4] * inv, acc[n][4 * g + 5] * inv);
-                    uint32_t b1 = E::pack2(acc[n][4 * g + 6] * inv, acc[n][4 * g + 7] * inv);
-                    auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-                    auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-                    const uint32_t x0 = r0[0], y0 = r0[1], x1 = r1[0], y1 = r1[1];
-                    ow[n][2 * g + 0] = x0; ow[n][2 * g + 1] = x1; ow[n][2 * g + 2] = y0; ow[n][2 * g + 3] = y1;
-                }
-        }
-        if (settle_next) settle_q();
-        if (wave_has_rows && my_q < seq_q) {
-            if (hh == 0 && lse_base != nullptr) {
-                const float lse = l_tot > 0.f ? (mc + fast_log2(l_tot)) * kLn2 : -INFINITY;
-                lse_base[my_q] = lse;
-            }
-            if (HAS_V) {
-                uint16_t *og = o_base + (int64_t)my_q * fwd_kernarg()->o_rs;
-#pragma unroll
-                for (int n = 0; n < NV; ++n)
-#pragma unroll
-                    for (int g = 0; g < 4; g += 2) {
-                        const int d0 = n * 32 + 8 * g + 8 * hh;
-                        if (d0 < p.d) {
-                            const u32x4 w = {ow[n][2 * g + 0], ow[n][2 * g + 1], ow[n][2 * g + 2], ow[n][2 * g + 3]};
-                            *reinterpret_cast<u32x4 *>(og + d0) = w;
-                        }
-                    }
-            }
-        }
-    };
-
-    // ---- first pass: nothing to overlap with yet ----------------------------------------------------------------------
-    FwdPass nxt;
-    nxt.valid = 0;
-    bool skip_wait = false;
-    // Start (or restart) the stream at `d` with no prefetch in flight: Q by plain loads, key tile 0 into `slot`.  Passes
-    // whose sequence has no key at all (nkb == 0) only write their zero rows / -inf LSE and are stepped over.
-    auto cold_start = [&](const int slot) {
-        while (cur.valid) {
-            begin_pass(cur);
-            if (cur.nkb > 0) break;
-            finish_pass(false);
-            cur = fwd_next_pass<C>(js, pass_ix);
-        }
-        if (!cur.valid) return false;
-        q_request(cur);
-        settle_q();
-        issue(kt - k_tile_stride, HAS_V ? vt - v_tile_stride : nullptr, partial_rows(seq_k, 0), slot);
-        skip_wait = false;
-        return true;
-    };
-
-    // One ring step on slot SLOT (compile-time: operand addresses fold into instruction offsets); the slots alternate for
-    // the whole launch, across pass seams.  Returns false when the workgroup's list is exhausted.
-    auto ring_step = [&](auto SLOT) -> bool {
-        constexpr int kSlot = decltype(SLOT)::value;
-        if (!skip_wait) wait_vmcnt<0>();        // my share of tile kb has landed (a prefetched tile 0 was waited for at the seam)
-        skip_wait = false;
-        __builtin_amdgcn_s_barrier();           // ... so has everybody's; all waves are done reading the other slot
-        const bool last = kb + 1 == nkb;
-        bool prefetched = false;
-        if (!last) {
-            issue(kt, vt, partial_rows(seq_k, kb + 1), kSlot ^ 1);
-            kt += k_tile_stride;
-            if (HAS_V) vt += v_tile_stride;
-        } else {
-            nxt = fwd_next_pass<C>(js, pass_ix);
-            if (nxt.valid && nxt.nkb > 0) {
-                const fwd_params_t kp = fwd_kernarg();
-                const uint16_t *nk = reinterpret_cast<const uint16_t *>(kp->k) + nxt.k_off + (int64_t)nxt.head * kp->k_hs;
-                const uint16_t *nv = HAS_V ? reinterpret_cast<const uint16_t *>(kp->v) + nxt.v_off + (int64_t)nxt.head * kp->v_hs
-                                           : nullptr;
-                issue(nk, nv, partial_rows(nxt.seq_k, 0), kSlot ^ 1);
-                q_touch(nxt);
-                prefetched = true;
-            }
-        }
-        const char *kbuf = smem + kSlot * C::STAGE;
-        const char *vbuf = kbuf + C::KTILE;
-        if (kb < my_nkb) tile(kb, kbuf, vbuf, kb == 0 || kb >= my_clean_end);
-        ++kb;
-        if (!last) return true;
-        // ---- pass seam ----
-        // The next pass's Q fragments: plain loads (the compiler owns their wait) issued HERE and nowhere else -- a request
-        // inside the tile code would leave "qf may be pending" on paths the compiler cannot rule out, and its waits would
-        // land in front of every S^T.  The rows were pulled into the L2 a whole step ago (q_touch), so the loads are L2
-        // hits that the epilogue arithmetic covers; the wait (settle_q: vmcnt(0), i.e. also the prefetched key tile) sits in
-        // front of the stores.
-        if (prefetched) q_request(nxt);
-        finish_pass(prefetched);
-        cur = nxt;
-        if (prefetched) {
-            begin_pass(cur);
-            skip_wait = true;
-            return true;
-        }
-        return cold_start(kSlot ^ 1);
-    };
-
-    if (!cold_start(0)) return;
-    for (;;) {
-        if (!ring_step(std::integral_constant<int, 0>{})) break;
-        if (!ring_step(std::integral_constant<int, 1>{})) break;
-    }
-}
-
-template <class ET, int KD, int NV, bool HAS_V, bool FULLD, bool DROP>
-__global__ __launch_bounds__((FlashDmaCfg<KD, NV, HAS_V>::NT), BP_FLASH_MINWAVES(NV, DROP))
-void flash_fwd_persistent_kernel(const FlashParams p) {
-    using C = FlashDmaCfg<KD, NV, HAS_V>;
-    __shared__ __attribute__((aligned(16))) char smem[C::NSTAGE * C::STAGE + C::NWAVE * 256];   // ring + q_touch scratch
-    flash_fwd_persistent<ET, KD, NV, HAS_V, FULLD, DROP>(p, smem, lds_base_addr(smem));
 }
 
 // Work order.  The dispatcher hands workgroups to the CUs of an XCD strictly round-robin and IN ORDER: block
@@ -1117,26 +598,6 @@ static hipError_t launch_one(const FlashParams &p, hipStream_t stream) {
     using C = FlashDmaCfg<KD, NV, HAS_V>;
     const int n_qtiles = (p.max_sq + C::BM - 1) / C::BM;
     const int grid = xcd_grid(p.b * p.h, (p.pair && n_qtiles > 1) ? (n_qtiles + 1) / 2 : n_qtiles);
-#if BP_FWD_PERSIST
-    if constexpr (C::NWAVE == 4) {
-        // resident workgroups: what the occupancy of this instantiation allows on every CU, a multiple of 8 (one list
-        // per XCD); a launch with fewer blocks than that keeps one workgroup per block
-        static const int resident = [] {
-            int per_cu = 0, dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, flash_fwd_persistent_kernel<ET, KD, NV, HAS_V, FULLD, DROP>,
-                                                             C::NT, 0) != hipSuccess || per_cu < 1)
-                return 0;
-            return (per_cu * prop.multiProcessorCount) / 8 * 8;
-        }();
-        if (resident >= 8) {
-            hipLaunchKernelGGL((flash_fwd_persistent_kernel<ET, KD, NV, HAS_V, FULLD, DROP>), dim3(std::min(grid, resident)),
-                               dim3(C::NT), 0, stream, p);
-            return hipGetLastError();
-        }
-    }
-#endif
     hipLaunchKernelGGL((flash_fwd_dma_kernel<ET, KD, NV, HAS_V, FULLD, DROP>), dim3(grid), dim3(C::NT), 0, stream, p);
     return hipGetLastError();
 }

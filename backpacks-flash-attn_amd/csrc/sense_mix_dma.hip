@@ -133,6 +133,13 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
                 // (sample-major order -- one sample's twelve jobs together -- fetches 4 % less and runs 2-3 % slower, r02_w)
                 // (table form, r04_ab: walking the queue column chunk by column chunk, so that the rows in flight chip-wide are
                 // one chunk's third of the table, is 1-2 % slower at B = 64 ... 2048 -- the memory-side cache does not pay it back)
+                // (round 6, S = 4096, review item "lockstep": -DBP_MIX_ORDER=1 hands out a group's query tiles as CONSECUTIVE
+                // tickets, heaviest first, so that the CUs of one XCD stream one (sample, column chunk) slab at a time --
+                // measured in profiles/r06_c_*; a development switch, the shipped order is the one below)
+#if defined(BP_MIX_ORDER) && BP_MIX_ORDER == 1
+                const int gl = idx / p.n_qtiles;
+                return mix_queue_group(p.n_chunks, q, gl) * 256 + (p.n_qtiles - 1 - (idx - gl * p.n_qtiles));
+#endif
                 const int slot = idx / groups;
                 const int grp = mix_queue_group(p.n_chunks, q, idx - slot * groups);
                 return grp * 256 + (p.n_qtiles - 1 - slot);

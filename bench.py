@@ -42,11 +42,17 @@ WORKLOADS = {
     'small-1024': ('small', 1024, 'bf16', 64),
     'small-4096-fp16': ('small', 4096, 'fp16', 8),
     'mini-k64-1024': ('mini-k64', 1024, 'bf16', 32),
+    # the few-sense ends of the reference's ablation (training/configs/experiment/owt/backpack-mini-flash-vecs-4.yaml, -vecs-1):
+    # wide senses, csrc/sense_wide.hip
+    'mini-k4-1024': ('mini-k4', 1024, 'bf16', 32),
+    'mini-k1-1024': ('mini-k1', 1024, 'bf16', 32),
     'micro-128': ('micro', 128, 'bf16', 4),
 }
 MODELS = {
     'micro': dict(n_embd=384, n_head=6, n_layer=6, num_content_vectors=16),
     'mini-k64': dict(n_embd=640, n_head=8, n_layer=8, num_content_vectors=64, shrink_final_inner=True),
+    'mini-k4': dict(n_embd=640, n_head=8, n_layer=8, num_content_vectors=4, shrink_final_inner=True),
+    'mini-k1': dict(n_embd=640, n_head=8, n_layer=8, num_content_vectors=1, shrink_final_inner=True),
     'small': dict(n_embd=768, n_head=12, n_layer=12, num_content_vectors=16),
 }
 

@@ -28,12 +28,14 @@
 extern "C" {
 #endif
 
-#define BP_ABI_VERSION 7   /* 2: *_dropout entry points added; 3: bias/GELU + column-sum entry points added, the
+#define BP_ABI_VERSION 8   /* 2: *_dropout entry points added; 3: bias/GELU + column-sum entry points added, the
                               persistent sense-mix launches take a caller-owned `queue_ws`; 4: bp_flash_bwd* take the
                               size of `dsum_ws` (bp_flash_bwd_ws_floats) and check it, queue_ws == NULL is refused
                               while the stream is capturing (BP_ERR_QUEUE_WS); 5: bp_dropout_add_layer_norm_scaled{,_bwd}
                               (rowscale / colscale of the reference's dropout_add_ln) added; 6: bp_sense_mix_gather added;
-                              7: bp_sense_mix_gather clamps row_index to the table and takes tables of at most 65 536 rows */
+                              7: bp_sense_mix_gather clamps row_index to the table and takes tables of at most 65 536 rows;
+                              8: bp_sense_lse / _alpha / _mix / _mix_weighted take sense widths d_k up to 640 (wide senses:
+                              the reference's vecs-4 / vecs-1 ablations), bp_build_flags() added */
 
 /* element type of q/k/v/out/content tensors */
 #define BP_DTYPE_F16 0
@@ -42,7 +44,7 @@ extern "C" {
 
 #define BP_OK 0
 #define BP_ERR_DTYPE -1       /* dtype is not BP_DTYPE_F16 / BP_DTYPE_BF16         (fmha_api.cpp:215-219) */
-#define BP_ERR_HEAD_DIM -2    /* head_dim < 1 or > 128                              (fmha_api.cpp:245)     */
+#define BP_ERR_HEAD_DIM -2    /* head_dim < 1 or > 128 (sense width d_k > 640)      (fmha_api.cpp:245)     */
 #define BP_ERR_SHAPE -3       /* batch/nheads/seqlen <= 0, or a required pointer is NULL (fmha_api.cpp:244-252) */
 #define BP_ERR_SCALE -4       /* softmax_scale is not finite or not > 0                                     */
 #define BP_ERR_LAUNCH -5      /* hipLaunchKernel failed (FMHA_CHECK_CUDA, src/fmha_utils.h:39)              */
@@ -58,6 +60,10 @@ typedef void *bp_stream_t; /* a hipStream_t */
 /* Human-readable text for a BP_ERR_* code (static storage). */
 const char *bp_strerror(int code);
 int bp_abi_version(void);
+/* 0 for a product build.  Bit 0: -DBP_FWD_WHATIF, bit 1: -DBP_BWD_WHATIF (timing builds that delete work on purpose:
+ * results are garbage), bit 2: -DBP_DEV_BUILD (run-time experiment switches compiled in).  A binding should refuse to
+ * load a library with bit 0 or 1 set as its default one. */
+int bp_build_flags(void);
 
 /*
  * bp_flash_fwd -- fused attention forward  O = softmax(scale * Q K^T [+ causal mask]) V  and the
@@ -148,6 +154,11 @@ int bp_attn_probs_dropout(const void *q, const void *k, const float *softmax_lse
  * (and time the passes separately).  The reference computes this inside torch.softmax
  * (training/src/models/backpack.py:122).
  *   lse (batch, nsenses, roundup(seqlen,16)) fp32, natural log.
+ * Sense widths (this entry point, bp_sense_alpha, bp_sense_mix, bp_sense_mix_weighted): 1 <= d_k <= 640.  Up to 128 the
+ * attention-class kernels run (LDS-DMA path for 16-byte friendly layouts); 129 ... 640 -- the reference's few-sense
+ * ablations, training/configs/experiment/owt/backpack-mini-flash-vecs-4.yaml (d_k = 160) and ...-vecs-1.yaml (640) --
+ * the wide kernels of csrc/sense_wide.hip (any alignment; d_k % 8 == 0 with 16-byte aligned rows takes 16-byte loads).
+ * bp_sense_mix_gather and the backward entry points stay at d_k <= 128.
  */
 int bp_sense_lse(const void *qk, float *lse, int batch, int seqlen, int nsenses, int d_k,
                  int64_t qk_batch_stride, int64_t qk_row_stride, int64_t qk_two_stride,

@@ -3,6 +3,8 @@
 // build: hipcc --offload-arch=gfx950 -O2 scripts/probes/mfma_peak.hip -o scripts/probes/mfma_peak.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
+#include <string>
 
 #define MF(a) "v_mfma_f32_32x32x16_bf16 v[" a "], v[64:67], v[68:71], v[" a "]\n"
 #define EXP4 "v_exp_f32 v80, v88\n v_exp_f32 v81, v89\n v_exp_f32 v82, v90\n v_exp_f32 v83, v91\n"
@@ -46,7 +48,34 @@ void run(const char *name, int wgs_per_cu) {
     hipFree(d);
 }
 
-int main() {
+// `mfma_peak.bin sustain MODE SECONDS`: one stream back to back for SECONDS (scripts/mfma_stream_clock.py samples the shader
+// clock and socket power meanwhile: the MFMA-only row of the power-limit evidence, round 6)
+template <int MODE>
+void sustain(double seconds) {
+    float *d; hipMalloc(&d, 4);
+    const int iters = 2000, grid = 256 * 4;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hipLaunchKernelGGL(spin<MODE>, dim3(grid), dim3(256), 0, 0, 10, d);
+    hipDeviceSynchronize();
+    double total_ms = 0; long n = 0;
+    while (total_ms < seconds * 1e3) {
+        hipEventRecord(a);
+        for (int i = 0; i < 8; ++i) hipLaunchKernelGGL(spin<MODE>, dim3(grid), dim3(256), 0, 0, iters, d);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        total_ms += ms; n += 8;
+    }
+    const double mfma = (double)grid * 4 * iters * 16 * n;
+    printf("{\"mode\": %d, \"launches\": %ld, \"ms\": %.3f, \"tflops\": %.1f}\n", MODE, n, total_ms, mfma * 32768.0 / total_ms / 1e9);
+    hipFree(d);
+}
+
+int main(int argc, char **argv) {
+    if (argc >= 4 && std::string(argv[1]) == "sustain") {
+        const int mode = atoi(argv[2]); const double sec = atof(argv[3]);
+        if (mode == 0) sustain<0>(sec); else if (mode == 1) sustain<1>(sec); else sustain<2>(sec);
+        return 0;
+    }
     for (int w : {1, 2, 3}) {
         run<0>("mfma only", w);
         run<1>("mfma + 2 exp + 2 fma per mfma", w);

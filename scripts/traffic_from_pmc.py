@@ -1,4 +1,4 @@
-"""HBM bytes per launch from a scripts/gpu_pmc.sh summary, written into profiles/traffic.json (what bench.py quotes
+"""HBM bytes per launch from a `scripts/gpu_run.sh pmc` summary, written into profiles/traffic.json (what bench.py quotes
 as roofline.traffic).  bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: rocprofv3 reports both in KiB and, on gfx950,
 FETCH_SIZE counts a wide coalesced read at half its size (MI355X_MICROARCH.md, section HBM).
     python scripts/traffic_from_pmc.py <summary.txt> <workload> <batch> [source note]"""
@@ -33,7 +33,7 @@ def main(summary, workload, batch, note=''):
     path = os.path.join(ROOT, 'profiles', 'traffic.json')
     table = json.load(open(path)) if os.path.exists(path) else {}
     table.pop('_comment', None)
-    table['_source'] = ('rocprofv3 --pmc passes of scripts/bench_kernels.py (scripts/gpu_pmc.sh), per-kernel averages in '
+    table['_source'] = ('rocprofv3 --pmc passes of scripts/bench_kernels.py (scripts/gpu_run.sh pmc; rounds 1-5: scripts/gpu_pmc.sh), per-kernel averages in '
                         'the profiles/*pmc* summary named per entry; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024')
     for kern, c in counters.items():
         name = bench_name(kern)

@@ -21,11 +21,12 @@ def test_library_exports_every_declared_symbol():
     handle = bp_hip.lib()
     names = declared_symbols()
     assert {'bp_flash_fwd', 'bp_attn_probs', 'bp_sense_lse', 'bp_sense_alpha', 'bp_sense_mix',
-            'bp_strerror', 'bp_abi_version'} <= set(names)
+            'bp_strerror', 'bp_abi_version', 'bp_build_flags'} <= set(names)
     for name in names:
         assert hasattr(handle, name), name
     assert set(bp_hip.SIGNATURES) == set(names)
     assert handle.bp_abi_version() == bp_hip.ABI_VERSION
+    assert handle.bp_build_flags() == 0       # a product build: no what-if timing switches, no dev switches
 
 
 def test_header_error_codes_have_messages():
@@ -69,7 +70,10 @@ def test_argument_validation_returns_before_any_launch():
     assert h.bp_flash_fwd_dropout(p, p, null, null, p, null, null, *tail, 0.1, p, null) == -7
     # sense mix: d_out < 1, d_k out of range
     assert h.bp_sense_mix(p, p, p, p, 0, 1, 16, 4, 16, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0.25, 1, null, null) == -6
-    assert h.bp_sense_mix(p, p, p, p, 0, 1, 16, 4, 200, 64, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0.25, 1, null, null) == -2
+    # (sense widths up to 640 are taken since ABI 8 -- csrc/sense_wide.hip; the gathering form stays at 128)
+    assert h.bp_sense_mix(p, p, p, p, 0, 1, 16, 4, 648, 64, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0.25, 1, null, null) == -2
+    assert h.bp_sense_lse(p, p, 1, 16, 4, 641, 1, 1, 1, 1, 0.25, 1, null) == -2
+    assert h.bp_sense_alpha(p, p, p, 0, 1, 16, 4, 0, 1, 1, 1, 1, 0.25, 1, null) == -2
     # a misaligned queue_ws
     assert h.bp_sense_mix(p, p, p, p, 0, 1, 16, 4, 16, 64, 8, 8, 8, 8, 8, 8, 8, 8, 8, 0.25, 1, ctypes.c_void_p(0x1004),
                           null) == -3

@@ -810,7 +810,7 @@ def test_wide_senses_backward_runs_without_opt_in():
     dout = torch.randn(b, s, d).bfloat16()
 
     def ref(dtype):
-        q_, c_ = qk.to(dtype).requires_grad_(), c.to(dtype).requires_grad_()
+        q_, c_ = qk.detach().to(dtype).clone().requires_grad_(), c.detach().to(dtype).clone().requires_grad_()
         alpha = R.sense_alpha_from_qk(q_)
         out = torch.einsum('blts,bsld->btd', alpha, c_)
         out.backward(dout.to(dtype))
@@ -818,7 +818,7 @@ def test_wide_senses_backward_runs_without_opt_in():
 
     o32, dq32, dc32 = ref(torch.float32)
     o16, dq16, dc16 = ref(torch.bfloat16)
-    q_, c_ = qk.to(DEV).requires_grad_(), c.to(DEV).requires_grad_()
+    q_, c_ = qk.detach().to(DEV).clone().requires_grad_(), c.detach().to(DEV).clone().requires_grad_()
     out = bp.sense_mix_autograd(q_, c_)
     out.backward(dout.to(DEV))
     for name, got, w32, w16 in (('out', out, o32, o16), ('dqk', q_.grad, dq32, dq16), ('dC', c_.grad, dc32, dc16)):

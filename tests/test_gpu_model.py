@@ -474,8 +474,8 @@ def test_block_with_stochastic_depth_against_the_fp32_eager_twin(fused):
     dz = torch.randn(b, s, dim, device=DEV, generator=g)
     outs = []
     for m, dt in ((ref, torch.float32), (blk, torch.bfloat16), (make(torch.bfloat16, False), torch.bfloat16)):
-        xi = x.to(dt).requires_grad_()
-        ri = res.clone().requires_grad_()          # the residual stream is fp32 in every variant
+        xi = x.detach().to(dt).clone().requires_grad_()
+        ri = res.detach().clone().requires_grad_()          # the residual stream is fp32 in every variant
         torch.manual_seed(11)
         h, r = m(xi, ri)
         (h.float() * dz + r.float() * dz).sum().backward()

@@ -501,3 +501,57 @@ def test_whole_vocabulary_sense_table_is_the_content_network_row_by_row_and_foll
     model.eval()
     # 'auto' verification: never for CPU tensors, on the GPU from `sense_table_verify_min_positions` positions up
     assert not t._verify_applies(ids)
+
+
+def test_stochastic_depth_and_block_drop_path_on_cpu():
+    """flash_attn/modules/block.py: StochasticDepth (torchvision's, restated: the image has no torchvision) drops whole
+    samples in training and is the identity in eval; Block wires it behind the dropout of both branches (reference
+    block.py:82-90,96-105); the state dict carries no new keys."""
+    from functools import partial
+    import torch.nn as nn
+    from flash_attn.modules.block import Block, StochasticDepth
+    from flash_attn.modules.mlp import Mlp
+    from src.models.backpack import Identity
+    sd = StochasticDepth(0.5, 'row').train()
+    torch.manual_seed(0)
+    x = torch.ones(64, 3, 5)
+    y = sd(x)
+    kept = y[:, 0, 0] != 0
+    assert 8 < kept.sum() < 56 and torch.all(y[kept] == 2.0) and torch.all(y[~kept] == 0.0)    # whole rows, scaled by 1/(1-p)
+    assert torch.equal(sd.eval()(x), x) and torch.equal(StochasticDepth(0.0).train()(x), x)
+    with pytest.raises(ValueError):
+        StochasticDepth(1.5)
+    blk = Block(16, Identity, partial(Mlp, hidden_features=32), norm_cls=nn.LayerNorm, prenorm=True, drop_path=0.5)
+    assert set(blk.state_dict()) == {'norm1.weight', 'norm1.bias', 'mlp.fc1.weight', 'mlp.fc1.bias', 'mlp.fc2.weight',
+                                     'mlp.fc2.bias', 'norm2.weight', 'norm2.bias'}
+    h, r = torch.randn(32, 4, 16), torch.randn(32, 4, 16)
+    blk.train()
+    torch.manual_seed(1)
+    h1, r1 = blk(h, r)
+    torch.manual_seed(1)
+    keep1 = torch.empty(32, 1, 1).bernoulli_(0.5) / 0.5           # the two draws of the block, in order
+    keep2 = torch.empty(32, 1, 1).bernoulli_(0.5) / 0.5
+    res1 = h * keep1 + r
+    mid = blk.norm1(res1)
+    res2 = blk.mlp(mid) * keep2 + res1
+    assert torch.allclose(r1, res2, atol=1e-6) and torch.allclose(h1, blk.norm2(res2), atol=1e-6)
+    blk.eval()
+    h2, r2 = blk(h, r)
+    assert torch.allclose(r2, blk.mlp(blk.norm1(h + r)) + h + r, atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        Block(16, Identity, prenorm=False)
+
+
+def test_bench_clock_power_sampler_without_a_gpu():
+    """bench.py's side-thread sampler: with nothing readable it reports source None and null means, never a guess."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), 'bench.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    s = mod.ClockPowerSampler(0, period_s=0.01).start()
+    out = s.stop()
+    assert set(out) >= {'sclk_mhz_mean', 'power_w_mean', 'power_cap_w', 'samples', 'source'}
+    if out['source'] is None:
+        assert out['sclk_mhz_mean'] is None and out['power_w_mean'] is None and out['samples'] == 0
