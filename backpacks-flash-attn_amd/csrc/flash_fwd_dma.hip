@@ -31,9 +31,11 @@
 #define BP_FWD_STREAM 1
 #endif
 // epilogue: O as 16-byte column groups (one v_permlane32_swap per dword pairs the half-waves' 8-byte pieces) instead of
-// 8-byte stores; measured in profiles/r06_c_ab_flash_wide_store.jsonl
+// 8-byte stores -- half the store instructions for the same bytes (the backward kernels' store_block16 has had this form
+// since round 3).  Same-box A/B, bit-identical on 137 cases (profiles/r06_c_ab_flash_wide_store.jsonl, r06_c_t21_bits.txt):
+// trunk shape B = 256 0.729 -> 0.707 ms, B = 2048 4.821 -> 4.688 ms (-2.8 %), S = 4096 +-0.5 %.  0 restores the 8-byte form.
 #ifndef BP_FWD_WIDE_STORE
-#define BP_FWD_WIDE_STORE 0
+#define BP_FWD_WIDE_STORE 1
 #endif
 #include "bp_common.h"
 #include "bp_dma.h"

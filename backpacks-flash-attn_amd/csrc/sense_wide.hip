@@ -20,24 +20,32 @@
 
 namespace bp {
 
-struct WideCfg {
+// KDT: compile-time bound of the 16-column steps of the sense width.  Two classes are instantiated:
+//   KDT = 12  (d_k <= 192, e.g. vecs-4's 160): the query fragments stay in REGISTERS for a whole sense (48 registers), the K
+//             tile is 12.8 KB, so three (mix) to six (LSE, alpha) workgroups share a CU;
+//   KDT = 40  (d_k <= 640, vecs-1): fragments re-fetched per key block in steps of 64 columns, 41.5 KB K tiles, one workgroup per CU.
+template <int KDT>
+struct WideCfgT {
     static constexpr int BM = 128;                 // queries per workgroup (4 waves x 32)
     static constexpr int BK = 32;                  // keys per block
     static constexpr int NT = 256;
-    static constexpr int KD_MAX = 40;              // 16-column steps: d_k <= 640
+    static constexpr int KD_MAX = KDT;
+    static constexpr bool QREG = KDT <= 12;        // query fragments of a sense held in registers
     static constexpr int KROW_MAX = KD_MAX * 32 + 16;
-    static constexpr int KTILE_MAX = BK * KROW_MAX;            // 41 472 bytes
-    static constexpr int K_ITERS_MAX = (BK * KD_MAX * 2 + NT - 1) / NT;   // 10 chunks of 16 bytes per thread
+    static constexpr int KTILE_MAX = BK * KROW_MAX;
+    static constexpr int K_ITERS_MAX = (BK * KD_MAX * 2 + NT - 1) / NT;   // 16-byte chunks per thread and tile
     static constexpr int NB = 4;                   // 32-column blocks of the output per workgroup (mix)
     static constexpr int CROW = NB * 64;
     static constexpr int CTILE = BK * CROW;        // 8 192 bytes
     static constexpr int CCH = NB * 4;
     static constexpr int C_ITERS = (BK * CCH + NT - 1) / NT;   // 2
 };
+constexpr int kWideSmallKd = 12, kWideLargeKd = 40;
 
 // K rows [kb*32, kb*32+32) of one sense -> registers -> LDS image (row pitch krow = 32*KD + 16 bytes: conflict-free b128)
-template <bool VEC>
+template <bool VEC, int KDT>
 struct WideKLoader {
+    using WideCfg = WideCfgT<KDT>;
     u32x4 reg[WideCfg::K_ITERS_MAX];
     BP_DEV void fetch(const uint16_t *kg, int64_t k_rs, int kb, int S, int dk, int kd, int tid) {
         const int kch = kd * 2;
@@ -65,32 +73,61 @@ struct WideKLoader {
     }
 };
 
-// S^T (32 keys x 32 queries) of one key block for my wave's 32 queries: st[r] = q[my_q] . k[kb*32 + (r&3) + 8*(r>>2) + 4*hh]
-template <class ET, bool VEC>
-BP_DEV f32x16 wide_scores(const char *kbuf, const uint16_t *qrow, bool q_valid, int dk, int kd, int l31, int hh) {
-    using E = Elem<ET>;
-    f32x16 st;
+// The query fragments of my row for one sense (B operand of S^T = K Q^T): column 16 s + 8 hh .. +7 of step s.
+template <bool VEC, int KDT>
+BP_DEV void wide_load_q(u32x4 (&qf)[KDT], const uint16_t *qrow, bool q_valid, int dk, int hh) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+    for (int s = 0; s < KDT; ++s) {
+        const int col = 16 * s + 8 * hh;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (q_valid && col < dk) v = VEC ? ld_global_16B(qrow + col) : ld_global_8x2B(qrow, col, dk);
+        qf[s] = v;
+    }
+}
+
+// S^T (32 keys x 32 queries) of one key block for my wave's 32 queries: st[r] = q[my_q] . k[kb*32 + (r&3) + 8*(r>>2) + 4*hh].
+// Two accumulation chains (even / odd steps) so that consecutive MFMAs do not wait for each other.
+// QREG: fragments from registers (qf, all KDT steps; steps >= kd hold zeros and are skipped); otherwise fetched from global
+// memory in steps of 64 columns -- L1 / L2 hits after the wave's first key block.
+template <class ET, bool VEC, int KDT>
+BP_DEV f32x16 wide_scores(const char *kbuf, const u32x4 (&qf)[KDT <= 12 ? KDT : 1], const uint16_t *qrow, bool q_valid, int dk,
+                          int kd, int l31, int hh) {
+    using E = Elem<ET>;
+    f32x16 st0, st1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { st0[r] = 0.f; st1[r] = 0.f; }
     const int krow = kd * 32 + 16;
     const int k_lane_off = l31 * krow + hh * 16;
-    for (int s0 = 0; s0 < kd; s0 += 4) {
-        u32x4 qv[4];
+    if constexpr (KDT <= 12) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = 16 * (s0 + j) + 8 * hh;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (q_valid && col < dk) v = VEC ? ld_global_16B(qrow + col) : ld_global_8x2B(qrow, col, dk);
-            qv[j] = v;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (s0 + j < kd) {
-                const u32x4 a = lds_read_16B(kbuf, k_lane_off + (s0 + j) * 32);
-                st = E::mfma(a, qv[j], st);
+        for (int s = 0; s < KDT; ++s)
+            if (s < kd) {
+                const u32x4 a = lds_read_16B(kbuf, k_lane_off + s * 32);
+                if (s & 1) st1 = E::mfma(a, qf[s], st1);
+                else st0 = E::mfma(a, qf[s], st0);
             }
+    } else {
+        for (int s0 = 0; s0 < kd; s0 += 4) {
+            u32x4 qv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = 16 * (s0 + j) + 8 * hh;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (q_valid && col < dk) v = VEC ? ld_global_16B(qrow + col) : ld_global_8x2B(qrow, col, dk);
+                qv[j] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (s0 + j < kd) {
+                    const u32x4 a = lds_read_16B(kbuf, k_lane_off + (s0 + j) * 32);
+                    if (j & 1) st1 = E::mfma(a, qv[j], st1);
+                    else st0 = E::mfma(a, qv[j], st0);
+                }
+        }
     }
-    return st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st0[r] += st1[r];
+    return st0;
 }
 
 struct WideParams {          // the three kernels' common part (all strides in 16-bit elements)
@@ -103,8 +140,9 @@ struct WideParams {          // the three kernels' common part (all strides in 1
 };
 
 // ---- LSE ------------------------------------------------------------------------------------------------------------
-template <class ET, bool VEC>
+template <class ET, bool VEC, int KDT>
 __global__ __launch_bounds__(256) void sense_lse_wide_kernel(const WideParams p) {
+    using WideCfg = WideCfgT<KDT>;
     __shared__ __attribute__((aligned(16))) char smem[2 * WideCfg::KTILE_MAX];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
@@ -125,7 +163,9 @@ __global__ __launch_bounds__(256) void sense_lse_wide_kernel(const WideParams p)
     const float c2 = p.scale_log2e;
     const uint16_t *qrow = qg + (int64_t)min(my_q, S - 1) * p.qk_rs;
 
-    WideKLoader<VEC> ld;
+    WideKLoader<VEC, KDT> ld;
+    u32x4 qf[WideCfg::QREG ? KDT : 1];
+    if constexpr (WideCfg::QREG) wide_load_q<VEC, KDT>(qf, qrow, my_q < S, dk, hh);
     float m_run = -INFINITY, l_run = 0.f;
     ld.fetch(kg, p.qk_rs, 0, S, dk, kd, tid);
     ld.stash(smem, kd, tid);
@@ -134,7 +174,7 @@ __global__ __launch_bounds__(256) void sense_lse_wide_kernel(const WideParams p)
         const int cur = kb & 1;
         if (kb + 1 < nkb) ld.fetch(kg, p.qk_rs, kb + 1, S, dk, kd, tid);
         if (wave_has_rows && kb <= my_last_kb) {
-            f32x16 st = wide_scores<ET, VEC>(smem + cur * ktile, qrow, my_q < S, dk, kd, l31, hh);
+            f32x16 st = wide_scores<ET, VEC, KDT>(smem + cur * ktile, qf, qrow, my_q < S, dk, kd, l31, hh);
             const int lim = min(S - 1, my_q) - kb * WideCfg::BK - 4 * hh;   // last visible key of my row, block-relative
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -169,9 +209,10 @@ struct WideAlphaParams {
     int vec_store;            // 8-byte stores of 4 keys are aligned (s % 4 == 0, base aligned)
 };
 
-template <class ET, bool VEC>
+template <class ET, bool VEC, int KDT>
 __global__ __launch_bounds__(256) void sense_alpha_wide_kernel(const WideAlphaParams pa) {
     using E = Elem<ET>;
+    using WideCfg = WideCfgT<KDT>;
     const WideParams &p = pa.w;
     __shared__ __attribute__((aligned(16))) char smem[2 * WideCfg::KTILE_MAX];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -210,7 +251,9 @@ __global__ __launch_bounds__(256) void sense_alpha_wide_kernel(const WideAlphaPa
         }
     };
 
-    WideKLoader<VEC> ld;
+    WideKLoader<VEC, KDT> ld;
+    u32x4 qf[WideCfg::QREG ? KDT : 1];
+    if constexpr (WideCfg::QREG) wide_load_q<VEC, KDT>(qf, qrow, my_q < S, dk, hh);
     ld.fetch(kg, p.qk_rs, 0, S, dk, kd, tid);
     ld.stash(smem, kd, tid);
     __syncthreads();
@@ -218,7 +261,7 @@ __global__ __launch_bounds__(256) void sense_alpha_wide_kernel(const WideAlphaPa
         const int cur = kb & 1;
         if (kb + 1 < nkb) ld.fetch(kg, p.qk_rs, kb + 1, S, dk, kd, tid);
         if (wave_has_rows && kb <= my_last_kb) {
-            f32x16 st = wide_scores<ET, VEC>(smem + cur * ktile, qrow, my_q < S, dk, kd, l31, hh);
+            f32x16 st = wide_scores<ET, VEC, KDT>(smem + cur * ktile, qf, qrow, my_q < S, dk, kd, l31, hh);
             const int lim = my_q - kb * WideCfg::BK - 4 * hh;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -245,10 +288,10 @@ __global__ __launch_bounds__(256) void sense_alpha_wide_kernel(const WideAlphaPa
 }
 
 // ---- fused mix -----------------------------------------------------------------------------------------------------------
-template <class ET, bool VEC_QK, bool VEC_C>
+template <class ET, bool VEC_QK, bool VEC_C, int KDT>
 __global__ __launch_bounds__(256) void sense_mix_wide_kernel(const MixParams p) {
     using E = Elem<ET>;
-    using W = WideCfg;
+    using W = WideCfgT<KDT>;
     __shared__ __attribute__((aligned(16))) char smem[2 * (W::KTILE_MAX + W::CTILE)];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
@@ -273,7 +316,8 @@ __global__ __launch_bounds__(256) void sense_mix_wide_kernel(const MixParams p) 
     const float c2 = p.scale_log2e;
     const int nb_live = min(W::NB, (p.dout - col_base + 31) / 32);
 
-    WideKLoader<VEC_QK> ld;
+    WideKLoader<VEC_QK, KDT> ld;
+    u32x4 qf[W::QREG ? KDT : 1];
     u32x4 creg[W::C_ITERS];
     auto fetch = [&](int step) {
         const int l = step / nkb, kb = step - l * nkb;
@@ -321,13 +365,15 @@ __global__ __launch_bounds__(256) void sense_mix_wide_kernel(const MixParams p) 
         const int cur = step & 1;
         const int l = step / nkb, kb = step - l * nkb;
         if (step + 1 < nsteps) fetch(step + 1);
-        if (kb == 0 && wave_has_rows)
+        const uint16_t *qrow = qg + (int64_t)min(my_q, S - 1) * p.qk_rs + (int64_t)l * p.qk_ss;
+        if (kb == 0 && wave_has_rows) {   // new sense: my row's log-sum-exp (and its fragments, when they live in registers)
             lse2 = (my_q < S) ? p.lse[((int64_t)batch * p.nsenses + l) * p.lse_stride + my_q] * kLog2e : 0.f;
+            if constexpr (W::QREG) wide_load_q<VEC_QK, KDT>(qf, qrow, my_q < S, dk, hh);
+        }
         if (wave_has_rows && kb <= my_last_kb) {
             const char *kbuf = smem + cur * stage;
             const char *cbuf = kbuf + ktile;
-            const uint16_t *qrow = qg + (int64_t)min(my_q, S - 1) * p.qk_rs + (int64_t)l * p.qk_ss;
-            f32x16 st = wide_scores<ET, VEC_QK>(kbuf, qrow, my_q < S, dk, kd, l31, hh);
+            f32x16 st = wide_scores<ET, VEC_QK, KDT>(kbuf, qf, qrow, my_q < S, dk, kd, l31, hh);
             const int lim = my_q - kb * W::BK - 4 * hh;
             const float *kw = p.kw != nullptr ? p.kw + batch * p.kw_bs + (int64_t)l * p.kw_ss : nullptr;
 #pragma unroll
@@ -393,18 +439,29 @@ static WideParams wide_params(const void *q, const void *k, float *lse, int64_t 
     return w;
 }
 
+// one instantiation per (dtype, alignment class, width class)
+#define BP_WIDE_DISPATCH(KERNEL, DTYPE, VEC, DK, ...)                                                          \
+    do {                                                                                                       \
+        const bool small_ = (DK) <= 16 * kWideSmallKd;                                                         \
+        if ((DTYPE) == 1) {                                                                                    \
+            if (VEC) { if (small_) hipLaunchKernelGGL((KERNEL<BF16, true, kWideSmallKd>), __VA_ARGS__);        \
+                       else hipLaunchKernelGGL((KERNEL<BF16, true, kWideLargeKd>), __VA_ARGS__); }             \
+            else { if (small_) hipLaunchKernelGGL((KERNEL<BF16, false, kWideSmallKd>), __VA_ARGS__);           \
+                   else hipLaunchKernelGGL((KERNEL<BF16, false, kWideLargeKd>), __VA_ARGS__); }                \
+        } else {                                                                                               \
+            if (VEC) { if (small_) hipLaunchKernelGGL((KERNEL<F16, true, kWideSmallKd>), __VA_ARGS__);         \
+                       else hipLaunchKernelGGL((KERNEL<F16, true, kWideLargeKd>), __VA_ARGS__); }              \
+            else { if (small_) hipLaunchKernelGGL((KERNEL<F16, false, kWideSmallKd>), __VA_ARGS__);            \
+                   else hipLaunchKernelGGL((KERNEL<F16, false, kWideLargeKd>), __VA_ARGS__); }                 \
+        }                                                                                                      \
+    } while (0)
+
 hipError_t launch_sense_lse_wide(const void *q, const void *k, float *lse, int64_t lse_stride, int64_t qk_bs,
                                  int64_t qk_rs, int64_t qk_ss, int b, int s, int nsenses, int dk, float scale_log2e,
                                  int dtype, bool vec, hipStream_t stream) {
     const WideParams w = wide_params(q, k, lse, lse_stride, qk_bs, qk_rs, qk_ss, b, s, nsenses, dk, scale_log2e);
-    const dim3 grid(xcd_grid(b * nsenses, (s + WideCfg::BM - 1) / WideCfg::BM)), block(WideCfg::NT);
-    if (dtype == 1) {
-        if (vec) hipLaunchKernelGGL((sense_lse_wide_kernel<BF16, true>), grid, block, 0, stream, w);
-        else hipLaunchKernelGGL((sense_lse_wide_kernel<BF16, false>), grid, block, 0, stream, w);
-    } else {
-        if (vec) hipLaunchKernelGGL((sense_lse_wide_kernel<F16, true>), grid, block, 0, stream, w);
-        else hipLaunchKernelGGL((sense_lse_wide_kernel<F16, false>), grid, block, 0, stream, w);
-    }
+    const dim3 grid(xcd_grid(b * nsenses, (s + 127) / 128)), block(256);
+    BP_WIDE_DISPATCH(sense_lse_wide_kernel, dtype, vec, dk, grid, block, 0, stream, w);
     return hipGetLastError();
 }
 
@@ -415,31 +472,31 @@ hipError_t launch_sense_alpha_wide(const void *q, const void *k, float *lse, int
     pa.w = wide_params(q, k, lse, lse_stride, qk_bs, qk_rs, qk_ss, b, s, nsenses, dk, scale_log2e);
     pa.alpha = static_cast<uint16_t *>(alpha);
     pa.vec_store = (s % 4 == 0) && ((reinterpret_cast<uintptr_t>(alpha) & 7) == 0);
-    const dim3 grid(xcd_grid(b * nsenses, (s + WideCfg::BM - 1) / WideCfg::BM)), block(WideCfg::NT);
-    if (dtype == 1) {
-        if (vec) hipLaunchKernelGGL((sense_alpha_wide_kernel<BF16, true>), grid, block, 0, stream, pa);
-        else hipLaunchKernelGGL((sense_alpha_wide_kernel<BF16, false>), grid, block, 0, stream, pa);
-    } else {
-        if (vec) hipLaunchKernelGGL((sense_alpha_wide_kernel<F16, true>), grid, block, 0, stream, pa);
-        else hipLaunchKernelGGL((sense_alpha_wide_kernel<F16, false>), grid, block, 0, stream, pa);
-    }
+    const dim3 grid(xcd_grid(b * nsenses, (s + 127) / 128)), block(256);
+    BP_WIDE_DISPATCH(sense_alpha_wide_kernel, dtype, vec, dk, grid, block, 0, stream, pa);
     return hipGetLastError();
 }
 
-template <class ET>
+template <class ET, int KDT>
 static hipError_t launch_mix_wide_et(const MixParams &p, bool vq, bool vc, hipStream_t stream) {
-    const int n_qtiles = (p.s + WideCfg::BM - 1) / WideCfg::BM;
-    const int n_chunks = (p.dout + WideCfg::NB * 32 - 1) / (WideCfg::NB * 32);
-    const dim3 grid(xcd_grid(p.b * n_chunks, n_qtiles)), block(WideCfg::NT);
-    if (vq && vc) hipLaunchKernelGGL((sense_mix_wide_kernel<ET, true, true>), grid, block, 0, stream, p);
-    else if (vq) hipLaunchKernelGGL((sense_mix_wide_kernel<ET, true, false>), grid, block, 0, stream, p);
-    else if (vc) hipLaunchKernelGGL((sense_mix_wide_kernel<ET, false, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((sense_mix_wide_kernel<ET, false, false>), grid, block, 0, stream, p);
+    using W = WideCfgT<KDT>;
+    const int n_qtiles = (p.s + W::BM - 1) / W::BM;
+    const int n_chunks = (p.dout + W::NB * 32 - 1) / (W::NB * 32);
+    const dim3 grid(xcd_grid(p.b * n_chunks, n_qtiles)), block(W::NT);
+    if (vq && vc) hipLaunchKernelGGL((sense_mix_wide_kernel<ET, true, true, KDT>), grid, block, 0, stream, p);
+    else if (vq) hipLaunchKernelGGL((sense_mix_wide_kernel<ET, true, false, KDT>), grid, block, 0, stream, p);
+    else if (vc) hipLaunchKernelGGL((sense_mix_wide_kernel<ET, false, true, KDT>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((sense_mix_wide_kernel<ET, false, false, KDT>), grid, block, 0, stream, p);
     return hipGetLastError();
 }
 
 hipError_t launch_sense_mix_wide(const MixParams &p, int dtype, bool vec_qk, bool vec_c, hipStream_t stream) {
-    return dtype == 1 ? launch_mix_wide_et<BF16>(p, vec_qk, vec_c, stream) : launch_mix_wide_et<F16>(p, vec_qk, vec_c, stream);
+    const bool small_ = p.dk <= 16 * kWideSmallKd;
+    if (dtype == 1)
+        return small_ ? launch_mix_wide_et<BF16, kWideSmallKd>(p, vec_qk, vec_c, stream)
+                      : launch_mix_wide_et<BF16, kWideLargeKd>(p, vec_qk, vec_c, stream);
+    return small_ ? launch_mix_wide_et<F16, kWideSmallKd>(p, vec_qk, vec_c, stream)
+                  : launch_mix_wide_et<F16, kWideLargeKd>(p, vec_qk, vec_c, stream);
 }
 
 }  // namespace bp

@@ -434,6 +434,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-threads', type=int, default=None)
     ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--eager-senses', action='store_true',
+                    help='comparison runs only: sense weights and combination of a WIDE-sense model (d_k > 128) as the '
+                         "reference's eager op sequence on the GPU instead of csrc/sense_wide.hip (what rounds 1-5 ran)")
     ap.add_argument('--no-clock-probe', action='store_true',
                     help='skip the sustained run of the dominant kernel alone that measures its shader clock / power')
     ap.add_argument('--content', default=None, choices=['batch', 'cached', 'position'],
@@ -474,6 +477,8 @@ def main():
 
     import bp_hip
     bp_hip.lib()   # fail loudly if the HIP extension is missing -- no fallback path exists
+    if args.eager_senses:
+        bp_hip.SENSE_MAX_DK = 128
 
     model_name, seq, dtype_name, default_batch = WORKLOADS[args.workload]
     dtype = torch.bfloat16 if dtype_name == 'bf16' else torch.float16
@@ -675,6 +680,7 @@ def main():
             'dtype': dtype_name,
             'data': 'synthetic token ids, random weights (reference init scheme)',
             'launch': 'hip-graph replay' if args.graph else 'eager launches',
+            **({'sense_path': 'eager op sequence (comparison run, --eager-senses)'} if args.eager_senses else {}),
             'config': {'workload': f'Backpack-{model_name} forward (ids -> logits), d={cfg.n_embd}, '
                                    f'{cfg.n_head} heads, {cfg.n_layer} layers, k={cfg.num_content_vectors} '
                                    f'senses, vocab {cfg.vocab_size}, seq {seq}',

@@ -108,9 +108,14 @@ def test_sense_kernels_on_drawn_shapes(seed):
     s = rnd.choice([1, 2, 31, 33, 63, 64, 65, 255, 256, 257, rnd.randint(1, 600), rnd.randint(1, 600)])
     k = rnd.randint(1, 20)
     dk = rnd.choice([8, 16, 24, 32, 40, 48, 56, 64, 10, 20, 12])
+    if rnd.random() < 0.2:      # wide senses (round 6, csrc/sense_wide.hip): few of them, 129 ... 640 wide, unaligned ones too
+        k, dk = rnd.randint(1, 4), rnd.choice([136, 160, 192, 200, 320, 636, 640, 130, 250])
+        qk_amp = 1.3 * (64 / dk) ** 0.25
+    else:
+        qk_amp = 1.3
     d = 8 * rnd.randint(1, 100)
     name = f'seed {seed}: {dtype} b={b} s={s} k={k} dk={dk} d={d}'
-    qk = (1.3 * torch.randn(b, s, 2, k, dk, device=DEV, generator=g)).to(dtype)
+    qk = (qk_amp * torch.randn(b, s, 2, k, dk, device=DEV, generator=g)).to(dtype)
     c = torch.randn(b, s, k, d, device=DEV, generator=g).to(dtype)
     scale = dk ** -0.5
     qk_h, c_h = qk.cpu(), c.cpu()
