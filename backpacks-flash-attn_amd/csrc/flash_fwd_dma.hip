@@ -476,6 +476,8 @@ BP_DEV void flash_fwd_tile(const FlashParams p, char *smem, const uint32_t lds0,
 
 
     if (nkb > 0) issue(0);
+    // (the first tile's DMA issued BEFORE the wait for the Q fragments, so that the two round trips of a pass's prologue
+    // overlap, was measured on its own in round 6: +-1 %, profiles/r06_e_ab_flash_issue_first.jsonl -- not kept)
     // One ring step; SLOT is the ring slot as a compile-time constant (the loop is unrolled by the ring depth), so
     // the LDS addresses of all operand reads fold into instruction offsets.
     auto ring_step = [&](int kb, auto SLOT) {

@@ -5,10 +5,11 @@
 // kernels, csrc/flash_attn/fmha_api.cpp:245) take: a query's fragments no longer fit the register file next to the
 // accumulators.  These three kernels cover them natively; same tile algebra as the rest of this directory (bp_common.h:
 // S^T = K Q^T on v_mfma_f32_32x32x16, one query per lane, P^T straight into the second GEMM), with two changes:
-//   * the S^T product runs over the sense width in steps of 64 columns whose Q fragments are fetched from global memory
-//     per (32-query wave, 32-key block) -- 4 x 16 bytes per lane and step, L1 / L2 hits after the first key block -- while
-//     the K rows of the block sit in LDS (32 keys x up to 1296 bytes);
-//   * d_k is a run-time loop bound, not a template parameter: one instantiation per dtype and alignment class.
+//   * a query's fragments for one sense stay in REGISTERS for the whole key sweep in both width classes -- 48 registers up
+//     to d_k = 192, 160 up to d_k = 640, where the workgroup's one wave per SIMD owns the whole 512-entry file and hipcc
+//     parks what exceeds the 256 architectural registers in accumulation registers (no scratch) -- while the K rows of a
+//     32-key block sit in LDS (up to 1296 bytes each);
+//   * d_k is a run-time loop bound inside its class: one instantiation per dtype, alignment class and width class.
 // With few senses this path is small next to the trunk (k = 1: 3 % of the Mini k = 64 mix flops), so the schedule is the
 // simple one of flash_fwd.hip / sense_mix.hip (tiles staged through registers into a double-buffered LDS image, one
 // __syncthreads per key block), not a ring.
@@ -21,16 +22,17 @@
 namespace bp {
 
 // KDT: compile-time bound of the 16-column steps of the sense width.  Two classes are instantiated:
-//   KDT = 12  (d_k <= 192, e.g. vecs-4's 160): the query fragments stay in REGISTERS for a whole sense (48 registers), the K
-//             tile is 12.8 KB, so three (mix) to six (LSE, alpha) workgroups share a CU;
-//   KDT = 40  (d_k <= 640, vecs-1): fragments re-fetched per key block in steps of 64 columns, 41.5 KB K tiles, one workgroup per CU.
+//   KDT = 12  (d_k <= 192, e.g. vecs-4's 160): 48 fragment registers, 12.8 KB K tiles, two (mix: registers) to six (LSE,
+//             alpha: LDS) workgroups per CU;
+//   KDT = 40  (d_k <= 640, vecs-1): 160 fragment registers (the first version re-fetched them per key block from the L2:
+//             33 ms per mix launch at Mini k = 1, B = 1024, profiles/r06_d_bench_mini_k1_native.json), 41.5 KB K tiles,
+//             one workgroup per CU.
 template <int KDT>
 struct WideCfgT {
     static constexpr int BM = 128;                 // queries per workgroup (4 waves x 32)
     static constexpr int BK = 32;                  // keys per block
     static constexpr int NT = 256;
     static constexpr int KD_MAX = KDT;
-    static constexpr bool QREG = KDT <= 12;        // query fragments of a sense held in registers
     static constexpr int KROW_MAX = KD_MAX * 32 + 16;
     static constexpr int KTILE_MAX = BK * KROW_MAX;
     static constexpr int K_ITERS_MAX = (BK * KD_MAX * 2 + NT - 1) / NT;   // 16-byte chunks per thread and tile
@@ -86,45 +88,23 @@ BP_DEV void wide_load_q(u32x4 (&qf)[KDT], const uint16_t *qrow, bool q_valid, in
 }
 
 // S^T (32 keys x 32 queries) of one key block for my wave's 32 queries: st[r] = q[my_q] . k[kb*32 + (r&3) + 8*(r>>2) + 4*hh].
-// Two accumulation chains (even / odd steps) so that consecutive MFMAs do not wait for each other.
-// QREG: fragments from registers (qf, all KDT steps; steps >= kd hold zeros and are skipped); otherwise fetched from global
-// memory in steps of 64 columns -- L1 / L2 hits after the wave's first key block.
-template <class ET, bool VEC, int KDT>
-BP_DEV f32x16 wide_scores(const char *kbuf, const u32x4 (&qf)[KDT <= 12 ? KDT : 1], const uint16_t *qrow, bool q_valid, int dk,
-                          int kd, int l31, int hh) {
+// Two accumulation chains (even / odd steps) so that consecutive MFMAs do not wait for each other; the fragments of the
+// steps >= kd hold zeros and are skipped.
+template <class ET, int KDT>
+BP_DEV f32x16 wide_scores(const char *kbuf, const u32x4 (&qf)[KDT], int kd, int l31, int hh) {
     using E = Elem<ET>;
     f32x16 st0, st1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { st0[r] = 0.f; st1[r] = 0.f; }
     const int krow = kd * 32 + 16;
     const int k_lane_off = l31 * krow + hh * 16;
-    if constexpr (KDT <= 12) {
 #pragma unroll
-        for (int s = 0; s < KDT; ++s)
-            if (s < kd) {
-                const u32x4 a = lds_read_16B(kbuf, k_lane_off + s * 32);
-                if (s & 1) st1 = E::mfma(a, qf[s], st1);
-                else st0 = E::mfma(a, qf[s], st0);
-            }
-    } else {
-        for (int s0 = 0; s0 < kd; s0 += 4) {
-            u32x4 qv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int col = 16 * (s0 + j) + 8 * hh;
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (q_valid && col < dk) v = VEC ? ld_global_16B(qrow + col) : ld_global_8x2B(qrow, col, dk);
-                qv[j] = v;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (s0 + j < kd) {
-                    const u32x4 a = lds_read_16B(kbuf, k_lane_off + (s0 + j) * 32);
-                    if (j & 1) st1 = E::mfma(a, qv[j], st1);
-                    else st0 = E::mfma(a, qv[j], st0);
-                }
+    for (int s = 0; s < KDT; ++s)
+        if (s < kd) {
+            const u32x4 a = lds_read_16B(kbuf, k_lane_off + s * 32);
+            if (s & 1) st1 = E::mfma(a, qf[s], st1);
+            else st0 = E::mfma(a, qf[s], st0);
         }
-    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) st0[r] += st1[r];
     return st0;
@@ -164,8 +144,8 @@ __global__ __launch_bounds__(256) void sense_lse_wide_kernel(const WideParams p)
     const uint16_t *qrow = qg + (int64_t)min(my_q, S - 1) * p.qk_rs;
 
     WideKLoader<VEC, KDT> ld;
-    u32x4 qf[WideCfg::QREG ? KDT : 1];
-    if constexpr (WideCfg::QREG) wide_load_q<VEC, KDT>(qf, qrow, my_q < S, dk, hh);
+    u32x4 qf[KDT];
+    wide_load_q<VEC, KDT>(qf, qrow, my_q < S, dk, hh);
     float m_run = -INFINITY, l_run = 0.f;
     ld.fetch(kg, p.qk_rs, 0, S, dk, kd, tid);
     ld.stash(smem, kd, tid);
@@ -174,7 +154,7 @@ __global__ __launch_bounds__(256) void sense_lse_wide_kernel(const WideParams p)
         const int cur = kb & 1;
         if (kb + 1 < nkb) ld.fetch(kg, p.qk_rs, kb + 1, S, dk, kd, tid);
         if (wave_has_rows && kb <= my_last_kb) {
-            f32x16 st = wide_scores<ET, VEC, KDT>(smem + cur * ktile, qf, qrow, my_q < S, dk, kd, l31, hh);
+            f32x16 st = wide_scores<ET, KDT>(smem + cur * ktile, qf, kd, l31, hh);
             const int lim = min(S - 1, my_q) - kb * WideCfg::BK - 4 * hh;   // last visible key of my row, block-relative
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -252,8 +232,8 @@ __global__ __launch_bounds__(256) void sense_alpha_wide_kernel(const WideAlphaPa
     };
 
     WideKLoader<VEC, KDT> ld;
-    u32x4 qf[WideCfg::QREG ? KDT : 1];
-    if constexpr (WideCfg::QREG) wide_load_q<VEC, KDT>(qf, qrow, my_q < S, dk, hh);
+    u32x4 qf[KDT];
+    wide_load_q<VEC, KDT>(qf, qrow, my_q < S, dk, hh);
     ld.fetch(kg, p.qk_rs, 0, S, dk, kd, tid);
     ld.stash(smem, kd, tid);
     __syncthreads();
@@ -261,7 +241,7 @@ __global__ __launch_bounds__(256) void sense_alpha_wide_kernel(const WideAlphaPa
         const int cur = kb & 1;
         if (kb + 1 < nkb) ld.fetch(kg, p.qk_rs, kb + 1, S, dk, kd, tid);
         if (wave_has_rows && kb <= my_last_kb) {
-            f32x16 st = wide_scores<ET, VEC, KDT>(smem + cur * ktile, qf, qrow, my_q < S, dk, kd, l31, hh);
+            f32x16 st = wide_scores<ET, KDT>(smem + cur * ktile, qf, kd, l31, hh);
             const int lim = my_q - kb * WideCfg::BK - 4 * hh;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -317,7 +297,7 @@ __global__ __launch_bounds__(256) void sense_mix_wide_kernel(const MixParams p) 
     const int nb_live = min(W::NB, (p.dout - col_base + 31) / 32);
 
     WideKLoader<VEC_QK, KDT> ld;
-    u32x4 qf[W::QREG ? KDT : 1];
+    u32x4 qf[KDT];
     u32x4 creg[W::C_ITERS];
     auto fetch = [&](int step) {
         const int l = step / nkb, kb = step - l * nkb;
@@ -368,12 +348,12 @@ __global__ __launch_bounds__(256) void sense_mix_wide_kernel(const MixParams p) 
         const uint16_t *qrow = qg + (int64_t)min(my_q, S - 1) * p.qk_rs + (int64_t)l * p.qk_ss;
         if (kb == 0 && wave_has_rows) {   // new sense: my row's log-sum-exp (and its fragments, when they live in registers)
             lse2 = (my_q < S) ? p.lse[((int64_t)batch * p.nsenses + l) * p.lse_stride + my_q] * kLog2e : 0.f;
-            if constexpr (W::QREG) wide_load_q<VEC_QK, KDT>(qf, qrow, my_q < S, dk, hh);
+            wide_load_q<VEC_QK, KDT>(qf, qrow, my_q < S, dk, hh);
         }
         if (wave_has_rows && kb <= my_last_kb) {
             const char *kbuf = smem + cur * stage;
             const char *cbuf = kbuf + ktile;
-            f32x16 st = wide_scores<ET, VEC_QK, KDT>(kbuf, qf, qrow, my_q < S, dk, kd, l31, hh);
+            f32x16 st = wide_scores<ET, KDT>(kbuf, qf, kd, l31, hh);
             const int lim = my_q - kb * W::BK - 4 * hh;
             const float *kw = p.kw != nullptr ? p.kw + batch * p.kw_bs + (int64_t)l * p.kw_ss : nullptr;
 #pragma unroll

@@ -40,6 +40,12 @@ HOT = [
     ('flash_bwd.o', 'flash_bwd_dkdv_kernel<BF16, 4, true, true>', 2),
     ('flash_bwd.o', 'flash_bwd_dq_kernel<BF16, 4, true, true>', 2),
     ('sense_mix_bwd.o', 'sense_mix_dc_kernel<BF16, 3, true>', 2),
+    # wide senses (the reference's vecs-4 / vecs-1 ablations): d_k <= 192 at two workgroups per CU; d_k <= 640 keeps its 160
+    # fragment registers in the unified file (one wave per SIMD) -- neither may touch scratch
+    ('sense_wide.o', 'sense_mix_wide_kernel<BF16, true, true, 12>', 2),
+    ('sense_wide.o', 'sense_mix_wide_kernel<BF16, true, true, 40>', 1),
+    ('sense_wide.o', 'sense_lse_wide_kernel<BF16, true, 12>', 3),
+    ('sense_wide.o', 'sense_lse_wide_kernel<BF16, true, 40>', 1),
 ]
 
 
