@@ -1,8 +1,40 @@
-"""Summarise a rocprofv3 --kernel-trace --stats run (rocpd sqlite .db) into a small text table:
-    python scripts/rocprof_summary.py gpurun_out/prof_x/**/*_results.db [skip_first_n_per_kernel]
-Per kernel name: calls, total ms, average us, share of GPU kernel time, VGPRs, LDS."""
+"""Summarise a rocprofv3 --kernel-trace --stats run into a small text table:
+    python scripts/rocprof_summary.py gpurun_out/prof_x/**/*_results.db [out.txt]      (rocpd sqlite output)
+    python scripts/rocprof_summary.py gpurun_out/<tag>_stats [out.txt]                  (--output-format csv: a directory)
+Per kernel name: calls, total ms, average us, share of GPU kernel time (+ VGPRs, LDS, grid from the database / the trace)."""
+import csv
+import glob
+import os
 import sqlite3
 import sys
+
+
+def main_csv(root, out=None):
+    """rocprofv3 --output-format csv: <root>/**/*_kernel_stats.csv (+ *_kernel_trace.csv for registers / LDS / grid)."""
+    stats = sorted(glob.glob(os.path.join(root, '**', '*_kernel_stats.csv'), recursive=True))
+    if not stats:
+        raise SystemExit('no *_kernel_stats.csv under ' + root)
+    rows = list(csv.DictReader(open(stats[0])))
+    extra = {}
+    for path in glob.glob(os.path.join(root, '**', '*_kernel_trace.csv'), recursive=True):
+        for r in csv.DictReader(open(path)):
+            name = r.get('Kernel_Name')
+            if name and name not in extra:
+                extra[name] = (r.get('VGPR_Count', ''), r.get('Accum_VGPR_Count', ''), r.get('LDS_Block_Size', ''),
+                               r.get('Grid_Size_X', r.get('Grid_Size', '')), r.get('Workgroup_Size_X', r.get('Workgroup_Size', '')))
+    total = sum(float(r['TotalDurationNs']) for r in rows)
+    lines = [f'# rocprofv3 --kernel-trace --stats summary of {stats[0]}', f'# total GPU kernel time {total / 1e6:.3f} ms',
+             '# (registers per kernel: scripts/kernel_resources.py reads them from the code objects; the trace csv reports another unit)',
+             f'{"calls":>7} {"total_ms":>10} {"avg_us":>10} {"min_us":>9} {"max_us":>9} {"share":>7} {"lds":>7} {"grid":>10} {"wg":>5}  name']
+    for r in rows[:40]:
+        vg, ag, lds, gx, wx = extra.get(r['Name'], ('', '', '', '', ''))
+        lines.append(f'{int(r["Calls"]):7d} {float(r["TotalDurationNs"]) / 1e6:10.3f} {float(r["AverageNs"]) / 1e3:10.2f} '
+                     f'{float(r["MinNs"]) / 1e3:9.2f} {float(r["MaxNs"]) / 1e3:9.2f} {float(r["Percentage"]):6.2f}% {lds:>7} '
+                     f'{gx:>10} {wx:>5}  {r["Name"][:150]}')
+    text = '\n'.join(lines)
+    print(text)
+    if out:
+        open(out, 'w').write(text + '\n')
 
 
 def main(path, out=None):
@@ -25,4 +57,7 @@ def main(path, out=None):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
+    if os.path.isdir(sys.argv[1]):
+        main_csv(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
+    else:
+        main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
