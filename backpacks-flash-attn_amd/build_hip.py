@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT_DIR = os.path.join(CSRC, 'build')
 LIB = os.path.join(HERE, 'bp_hip', 'libbackpack_hip.so')
-SOURCES = ['flash_fwd.hip', 'flash_fwd_dma.hip', 'flash_bwd.hip', 'sense_mix.hip', 'sense_mix_dma.hip', 'sense_mix_bwd.hip', 'sense_wide.hip', 'attn_probs.hip',
+SOURCES = ['flash_fwd.hip', 'flash_fwd_dma.hip', 'flash_bwd.hip', 'sense_mix.hip', 'sense_mix_dma.hip', 'sense_mix_bwd.hip', 'sense_wide.hip', 'sense_wide_dma.hip', 'attn_probs.hip',
            'add_layer_norm.hip', 'xentropy.hip', 'softmax_bwd.hip', 'bias_gelu.hip', 'bp_api.hip']
 HEADERS = ['bp_common.h', 'bp_dma.h', 'bp_kernels.h', 'bp_philox.h', os.path.join('..', '..', 'include', 'bp_hip.h')]
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has one unified file); without it

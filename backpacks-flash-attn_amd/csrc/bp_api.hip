@@ -237,7 +237,10 @@ static int sense_lse(const void *qk, float *lse_ws, int batch, int seqlen, int n
     const bool vec = (d_k % 8 == 0) && aligned16(qp) && aligned16(kp) && mult8(qk_bs) && mult8(qk_rs) &&
                      mult8(qk_ss);
     hipError_t e;
-    if (d_k > 128)   // wide senses (sense_wide.hip): the reference's vecs-4 / vecs-1 ablations
+    if (d_k > 128 && bp::sense_wide_dma_takes(seqlen, d_k, 8, vec, true, false))   // d_k = 160 / 640: sense_wide_dma.hip
+        e = bp::launch_sense_lse_wide_dma(qp, kp, lse_ws, p.lse_stride, qk_bs, qk_rs, qk_ss, batch, seqlen, nsenses, d_k,
+                                          p.scale_log2e, dtype, stream);
+    else if (d_k > 128)   // wide senses (sense_wide.hip): the reference's vecs-4 / vecs-1 ablations
         e = bp::launch_sense_lse_wide(qp, kp, lse_ws, p.lse_stride, qk_bs, qk_rs, qk_ss, batch, seqlen, nsenses, d_k,
                                       p.scale_log2e, dtype, vec, stream);
     else e = dispatch_flash(p, dtype, vec, stream);
@@ -347,7 +350,9 @@ int bp_sense_mix_weighted(const void *qk, const void *content, const float *key_
                        mult8(c_row_stride) && mult8(c_sense_stride) && mult8(o_batch_stride) &&
                        mult8(o_row_stride);
     hipError_t e;
-    if (d_k > 128) e = bp::launch_sense_mix_wide(p, dtype, vec_qk, vec_c, st);   // few wide senses: sense_wide.hip
+    if (d_k > 128 && bp::sense_wide_dma_takes(seqlen, d_k, d_out, vec_qk, vec_c, key_weight != nullptr))
+        e = bp::launch_sense_mix_wide_dma(p, dtype, st);                         // d_k = 160 / 640: sense_wide_dma.hip
+    else if (d_k > 128) e = bp::launch_sense_mix_wide(p, dtype, vec_qk, vec_c, st);   // few wide senses: sense_wide.hip
     else if (vec_qk && vec_c && p.n_qtiles <= 256 && !dev_force_staged_mix()) e = bp::launch_sense_mix_dma(p, dtype, st);
     else e = bp::launch_sense_mix(p, dtype, vec_qk, vec_c, st);
     return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;

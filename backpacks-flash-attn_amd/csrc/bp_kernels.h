@@ -229,5 +229,12 @@ hipError_t launch_sense_alpha_wide(const void *q, const void *k, float *lse, int
                                    int64_t qk_bs, int64_t qk_rs, int64_t qk_ss, int b, int s, int nsenses, int dk,
                                    float scale_log2e, int dtype, bool vec, hipStream_t stream);
 hipError_t launch_sense_mix_wide(const MixParams &p, int dtype, bool vec_qk, bool vec_c, hipStream_t stream);
+// LDS-DMA ring versions for the reference's two few-sense configurations exactly (d_k = 160 / 640, 16-byte friendly
+// operands, s % 32 == 0): sense_wide_dma.hip
+bool sense_wide_dma_takes(int s, int dk, int dout, bool vec_qk, bool vec_c, bool weighted);
+hipError_t launch_sense_mix_wide_dma(const MixParams &p, int dtype, hipStream_t stream);
+hipError_t launch_sense_lse_wide_dma(const void *q, const void *k, float *lse, int64_t lse_stride, int64_t qk_bs,
+                                     int64_t qk_rs, int64_t qk_ss, int b, int s, int nsenses, int dk, float scale_log2e,
+                                     int dtype, hipStream_t stream);
 
 }  // namespace bp

@@ -1,0 +1,363 @@
+// Wide senses, fast path: the reference's two few-sense configurations exactly -- backpack-mini-flash-vecs-4.yaml (k = 4,
+// d_k = 160) and ...-vecs-1.yaml (k = 1, d_k = 640), training/configs/experiment/owt/ -- on 16-byte friendly operands with
+// S a multiple of 32.  Everything else wider than 128 keeps the general kernels of sense_wide.hip.
+//
+//   sense_mix_wide_dma_kernel   out = sum_l softmax_causal(q_l k_l^T / sqrt(d_k)) C_l, alpha never stored  (backpack.py:313)
+//   sense_lse_wide_dma_kernel   log-sum-exp of every (sense, query) row                                      (backpack.py:116-122)
+//
+// Same tile algebra as the rest of this directory (bp_common.h: S^T = K Q^T on v_mfma_f32_32x32x16, one query per lane,
+// P^T straight into the second GEMM).  What differs from sense_wide.hip, whose schedule is the simple staged one
+// (registers -> LDS, one __syncthreads per key block, 128 output columns per workgroup: S^T recomputed five times for
+// d = 640, every MFMA behind its own LDS round trip):
+//   * the K rows and the content rows of a 32-key block reach LDS by DMA (`global_load_lds_dwordx4`, bp_dma.h) into a
+//     two-slot ring: block i + 1 is in flight while block i is multiplied; one s_barrier per block;
+//   * a workgroup covers NB * 32 = 320 (or 160) output columns, so S^T and the exponentials are recomputed 2 (4) times per
+//     query block instead of 5;
+//   * the LDS operands of both MFMA runs are requested two MFMAs ahead (mfma_stream, bp_common.h);
+//   * the K image has an ODD row pitch (2 KD + 1 sixteen-byte slots): b128 reads of 16 consecutive rows touch every bank
+//     once; the content image is XOR-swizzled on the DMA's source side for ds_read_b64_tr_b16.
+// Algorithmic work per launch: 2 pairs (d_k + d) k B flop; bytes as SURVEY section 8(d): (4 + 2k + 2) S d B.
+#include "bp_common.h"
+#include "bp_dma.h"
+#include "bp_kernels.h"
+
+namespace bp {
+
+template <int KD, int NW, int NB>
+struct WideDmaCfg {
+    static constexpr int BK = 32;                      // keys per ring step
+    static constexpr int NT = NW * 64;
+    static constexpr int BM = NW * 32;                 // queries per workgroup (a wave owns 32)
+    static constexpr int KSLOTS = 2 * KD + 1;          // 16-byte slots per K row, one of them padding (odd pitch)
+    static constexpr int KROW = KSLOTS * 16;
+    static constexpr int K_PIECES = (BK * KSLOTS + 63) / 64;     // 1-KiB DMA pieces; the K region is whole pieces
+    static constexpr int KREGION = K_PIECES * 1024;
+    static constexpr int CSLOTS = NB * 4;              // 16-byte slots per content row
+    static constexpr int CROW = CSLOTS * 16;
+    static constexpr int C_PIECES = BK * CSLOTS / 64;  // 2 NB (0 for the LSE kernel: K only)
+    static constexpr int PIECES = K_PIECES + C_PIECES;
+    static constexpr int NPW = (PIECES + NW - 1) / NW; // DMA instructions per wave and step (the last wave may own fewer)
+    static constexpr int STAGE = PIECES * 1024;
+    static_assert(2 * STAGE <= 160 * 1024, "LDS budget");
+};
+
+// byte offset of (row, logical 16-byte chunk ch) in a content image of NB 64-byte chunks per row; ds_read_b64_tr_b16 serves
+// 32 lanes = 4 consecutive rows x 64 B at once, the four row segments must lie in four different quarters of the banks:
+//   NB = 5: rows are 320 B = 5 quarters apart -- distinct by construction;
+//   NB = 10: 640 B = 10 quarters -- rows r and r + 2 would collide: chunk index XOR ((row >> 1) & 1).
+template <int NB> BP_DEV int wide_c_off(int row, int ch) {
+    static_assert(NB == 5 || NB == 10, "swizzle derived for 5 and 10 column blocks");
+    int c64 = ch >> 2;
+    if (NB == 10) c64 ^= (row >> 1) & 1;
+    return row * (NB * 64) + ((c64 << 2) | (ch & 3)) * 16;
+}
+
+// The ring: per-lane source offsets of my DMA pieces (constant over the sweep), and the issue of one step's pieces.
+template <int KD, int NW, int NB>
+struct WideRing {
+    using C = WideDmaCfg<KD, NW, NB>;
+    uint32_t voff[C::NPW];
+    BP_DEV void setup(int wave, int lane, int64_t k_rs, int64_t c_rs, int col_base, int dout) {
+#pragma unroll
+        for (int j = 0; j < C::NPW; ++j) {
+            const int pi = wave * C::NPW + j;
+            const int g = pi * 64 + lane;                     // K region: linear slot -> (row, chunk); pad slots and the
+            const int krow = min(g / C::KSLOTS, C::BK - 1);   // region's tail re-fetch a valid chunk (never read)
+            const int kch = min(g - (g / C::KSLOTS) * C::KSLOTS, 2 * KD - 1);
+            uint32_t off = (uint32_t)(krow * k_rs + kch * 8) * 2u;
+            if constexpr (NB > 0) if (pi >= C::K_PIECES) {
+                const int c = (pi - C::K_PIECES) * 64 + lane;
+                const int row = c / C::CSLOTS, stored = c - row * C::CSLOTS;
+                int c64 = stored >> 2;
+                if (NB == 10) c64 ^= (row >> 1) & 1;
+                int col = col_base + ((c64 << 2) | (stored & 3)) * 8;
+                if (col >= dout) col = col_base;              // columns past d_out: any finite data (never stored)
+                off = (uint32_t)(row * c_rs + col) * 2u;
+            }
+            voff[j] = off;
+        }
+    }
+    BP_DEV void issue(int wave, uint32_t stage, const uint16_t *kt, const uint16_t *ct) const {
+#pragma unroll
+        for (int j = 0; j < C::NPW; ++j) {
+            const int pi = wave * C::NPW + j;
+            if (pi < C::PIECES)
+                dma16_s((NB > 0 && pi >= C::K_PIECES) ? ct : kt, voff[j],
+                        __builtin_amdgcn_readfirstlane(stage + pi * 1024));
+        }
+    }
+};
+
+// S^T (32 keys x 32 queries) of the block in `kbuf`: two accumulation chains, operands two MFMAs ahead
+template <class ET, int KD, int KROW>
+BP_DEV f32x16 wide_dma_scores(const char *kbuf, const u32x4 (&qf)[KD], int l31, int hh) {
+    using E = Elem<ET>;
+    f32x16 st0, st1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { st0[r] = 0.f; st1[r] = 0.f; }
+    const int k_lane_off = l31 * KROW + hh * 16;
+    mfma_stream<KD>([&](int i) { return lds_read_16B(kbuf, k_lane_off + i * 32); },
+                    [&](int i, const u32x4 &a) {
+                        if (i & 1) st1 = E::mfma(a, qf[i], st1);
+                        else st0 = E::mfma(a, qf[i], st0);
+                    });
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st0[r] += st1[r];
+    return st0;
+}
+
+template <int KD> BP_DEV void wide_dma_load_q(u32x4 (&qf)[KD], const uint16_t *qrow, int hh) {
+#pragma unroll
+    for (int s = 0; s < KD; ++s) qf[s] = ld_global_16B(qrow + 16 * s + 8 * hh);
+#pragma unroll
+    for (int s = 0; s < KD; ++s) settle(qf[s]);
+}
+
+// ---- fused mix ---------------------------------------------------------------------------------------------------------
+template <class ET, int KD, int NW, int NB>
+__global__ __launch_bounds__(NW * 64) void sense_mix_wide_dma_kernel(const MixParams p) {
+    using C = WideDmaCfg<KD, NW, NB>;
+    using E = Elem<ET>;
+    __shared__ __attribute__((aligned(16))) char smem[2 * C::STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int S = p.s;
+    const uint32_t lds0 = lds_base_addr(smem);
+    const int n_qtiles = (S + C::BM - 1) / C::BM;
+    const int n_chunks = (p.dout + NB * 32 - 1) / (NB * 32);
+    int grp, slot;
+    if (!xcd_map(blockIdx.x, p.b * n_chunks, n_qtiles, grp, slot)) return;
+    const int qt = n_qtiles - 1 - slot;               // heaviest query tiles first
+    const int batch = grp / n_chunks, chunk = grp - batch * n_chunks;
+    const int col_base = chunk * NB * 32;
+    const uint16_t *qg = reinterpret_cast<const uint16_t *>(p.q) + batch * p.qk_bs;
+    const uint16_t *kg = reinterpret_cast<const uint16_t *>(p.k) + batch * p.qk_bs;
+    const uint16_t *cg = reinterpret_cast<const uint16_t *>(p.c) + batch * p.c_bs;
+    const int k_end = min(S, qt * C::BM + C::BM);
+    const int nkb = k_end / C::BK;                    // S % 32 == 0 (launcher)
+    const int nsteps = p.nsenses * nkb;
+    const int q0 = qt * C::BM + wave * 32, my_q = q0 + l31;
+    const bool wave_has_rows = q0 < S;                // then every row of the wave exists
+    const int my_last_kb = q0 / C::BK;
+    const float c2 = p.scale_log2e;
+    const int nb_live = min(NB, (p.dout - col_base + 31) / 32);
+
+    WideRing<KD, NW, NB> ring;
+    ring.setup(wave, lane, p.qk_rs, p.c_rs, col_base, p.dout);
+    int l_i = 0, kb_i = 0;                            // (sense, key block) of the next issue
+    auto issue = [&](int step) {
+        const uint16_t *kt = kg + (int64_t)l_i * p.qk_ss + (int64_t)kb_i * C::BK * p.qk_rs;
+        const uint16_t *ct = cg + (int64_t)l_i * p.c_ss + (int64_t)kb_i * C::BK * p.c_rs;
+        ring.issue(wave, lds0 + (step & 1) * C::STAGE, kt, ct);
+        if (++kb_i == nkb) { kb_i = 0; ++l_i; }
+    };
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    // content fragments (A operand of O^T = C^T P^T): lane -> (row, 16-byte chunk) of the 4 x 64 B a tr read serves
+    const int c_row_lane = 4 * hh + ((lane & 15) >> 2);
+    const int c_ch_lane = ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1);
+    const int c_sub = (lane & 1) * 8;
+    // block n's chunk index is n ^ b (NB = 10; b = (row >> 1) & 1, the same for row + 8 and row + 16): two lane offsets,
+    // the rest are instruction offsets
+    const int c_off_even = wide_c_off<NB>(c_row_lane, c_ch_lane) + c_sub;
+    const int c_off_odd = wide_c_off<NB>(c_row_lane, 4 + c_ch_lane) + c_sub - 64;
+    auto c_read_off = [&](int n) { return ((NB == 10 && (n & 1)) ? c_off_odd : c_off_even) + n * 64; };
+
+    u32x4 qf[KD];
+    float lse2 = 0.f;
+    const uint16_t *qrow = qg + (int64_t)min(my_q, S - 1) * p.qk_rs;
+
+    issue(0);
+    for (int step = 0; step < nsteps; ++step) {
+        const int l = step / nkb, kb = step - l * nkb;
+        wait_vmcnt<0>();                   // my pieces of this step's block have landed ...
+        __builtin_amdgcn_s_barrier();      // ... so have everybody's; nobody reads the other slot any more
+        if (kb == 0 && wave_has_rows) {    // a new sense: my row's fragments and log-sum-exp (before the next DMA is in flight:
+                                           // the compiler's wait for them must not drain the ring)
+            wide_dma_load_q<KD>(qf, qrow + (int64_t)l * p.qk_ss, hh);
+            lse2 = p.lse[((int64_t)batch * p.nsenses + l) * p.lse_stride + my_q] * kLog2e;
+            settle(lse2);
+        }
+        if (step + 1 < nsteps) issue(step + 1);
+        if (wave_has_rows && kb <= my_last_kb) {
+            const char *kbuf = smem + (step & 1) * C::STAGE;
+            const char *cbuf = kbuf + C::KREGION;
+            f32x16 st = wide_dma_scores<ET, KD, C::KROW>(kbuf, qf, l31, hh);
+            u32x4 pf[2];
+            if (kb == my_last_kb) {        // the diagonal block: exact zeros above the diagonal
+                const int lim = l31 - 4 * hh;   // my_q - kb * 32 - 4 hh
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = ks * 8 + 2 * i;
+                        float e0 = fast_exp2(fmaf(st[r], c2, -lse2)), e1 = fast_exp2(fmaf(st[r + 1], c2, -lse2));
+                        if ((r & 3) + 8 * (r >> 2) > lim) e0 = 0.f;
+                        if (((r + 1) & 3) + 8 * ((r + 1) >> 2) > lim) e1 = 0.f;
+                        pf[ks][i] = E::pack2(e0, e1);
+                    }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = ks * 8 + 2 * i;
+                        pf[ks][i] = E::pack2(fast_exp2(fmaf(st[r], c2, -lse2)), fast_exp2(fmaf(st[r + 1], c2, -lse2)));
+                    }
+            }
+            mfma_stream<2 * NB>(
+                [&](int i) {
+                    const int ks = i / NB, n = i - ks * NB;
+                    const int off = c_read_off(n) + ks * 16 * C::CROW;
+                    const u32x2 lo = lds_read_tr16_8B(cbuf, off);
+                    const u32x2 hi = lds_read_tr16_8B(cbuf, off + 8 * C::CROW);
+                    return u32x4{lo[0], lo[1], hi[0], hi[1]};
+                },
+                [&](int i, const u32x4 &a) {
+                    const int ks = i / NB, n = i - ks * NB;
+                    if (n < nb_live) acc[n] = E::mfma(a, pf[ks], acc[n]);
+                });
+        }
+    }
+
+    if (!wave_has_rows) return;
+    uint16_t *og = reinterpret_cast<uint16_t *>(p.o) + batch * p.o_bs + (int64_t)my_q * p.o_rs;
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = col_base + n * 32 + 8 * g + 4 * hh;   // d_out % 8 == 0: a group of 4 is inside or outside
+            if (col < p.dout) {
+                const u32x2 w = {E::pack2(acc[n][4 * g + 0], acc[n][4 * g + 1]), E::pack2(acc[n][4 * g + 2], acc[n][4 * g + 3])};
+                *reinterpret_cast<u32x2 *>(og + col) = w;
+            }
+        }
+}
+
+// ---- LSE ---------------------------------------------------------------------------------------------------------------
+template <class ET, int KD, int NW>
+__global__ __launch_bounds__(NW * 64) void sense_lse_wide_dma_kernel(const MixParams p, float *lse_out) {
+    using C = WideDmaCfg<KD, NW, 0>;
+    __shared__ __attribute__((aligned(16))) char smem[2 * C::STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int S = p.s;
+    const uint32_t lds0 = lds_base_addr(smem);
+    const int n_qtiles = (S + C::BM - 1) / C::BM;
+    int grp, slot;
+    if (!xcd_map(blockIdx.x, p.b * p.nsenses, n_qtiles, grp, slot)) return;
+    const int qt = n_qtiles - 1 - slot;
+    const int batch = grp / p.nsenses, l = grp - batch * p.nsenses;
+    const uint16_t *qg = reinterpret_cast<const uint16_t *>(p.q) + batch * p.qk_bs + (int64_t)l * p.qk_ss;
+    const uint16_t *kg = reinterpret_cast<const uint16_t *>(p.k) + batch * p.qk_bs + (int64_t)l * p.qk_ss;
+    const int k_end = min(S, qt * C::BM + C::BM);
+    const int nkb = k_end / C::BK;
+    const int q0 = qt * C::BM + wave * 32, my_q = q0 + l31;
+    const bool wave_has_rows = q0 < S;
+    const int my_last_kb = q0 / C::BK;
+    const float c2 = p.scale_log2e;
+
+    WideRing<KD, NW, 0> ring;
+    ring.setup(wave, lane, p.qk_rs, 0, 0, 0);
+    u32x4 qf[KD];
+    if (wave_has_rows) wide_dma_load_q<KD>(qf, qg + (int64_t)min(my_q, S - 1) * p.qk_rs, hh);
+    float m_run = -INFINITY, l_run = 0.f;
+    ring.issue(wave, lds0, kg, kg);
+    for (int kb = 0; kb < nkb; ++kb) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kb + 1 < nkb)
+            ring.issue(wave, lds0 + ((kb + 1) & 1) * C::STAGE, kg + (int64_t)(kb + 1) * C::BK * p.qk_rs, kg);
+        if (wave_has_rows && kb <= my_last_kb) {
+            f32x16 st = wide_dma_scores<ET, KD, C::KROW>(smem + (kb & 1) * C::STAGE, qf, l31, hh);
+            if (kb == my_last_kb) {
+                const int lim = l31 - 4 * hh;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((r & 3) + 8 * (r >> 2) > lim) st[r] = -INFINITY;
+            }
+            float mxa = fmaxf(st[0], st[1]), mxb = fmaxf(st[2], st[3]);
+#pragma unroll
+            for (int r = 4; r < 16; r += 2) { mxa = fmaxf(mxa, st[r]); mxb = fmaxf(mxb, st[r + 1]); }
+            const float mx = xhalf_max(fmaxf(mxa, mxb));       // finite: key kb * 32 is visible to every row of the block
+            const float m_new = fmaxf(m_run, mx);
+            const float mc = m_new * c2;
+            const float alpha = fast_exp2(m_run * c2 - mc);    // 0 for a fresh row (m_run = -inf)
+            m_run = m_new;
+            float rs0 = 0.f, rs1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                rs0 += fast_exp2(fmaf(st[r], c2, -mc));
+                rs1 += fast_exp2(fmaf(st[r + 1], c2, -mc));
+            }
+            l_run = l_run * alpha + (rs0 + rs1);
+        }
+    }
+    if (!wave_has_rows) return;
+    const float l_tot = xhalf_sum(l_run);
+    if (hh == 0)
+        lse_out[((int64_t)batch * p.nsenses + l) * p.lse_stride + my_q] =
+            l_tot > 0.f ? (m_run * c2 + fast_log2(l_tot)) * kLn2 : -INFINITY;
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------------------------
+// d_k = 160: eight waves x 160 columns (256 queries share a block's K and content rows; two waves per SIMD);
+// d_k = 640: four waves x 320 columns (160 fragment + 160 accumulator registers: one wave per SIMD owns the file).
+#ifndef BP_WIDE160_NW
+#define BP_WIDE160_NW 8
+#endif
+#ifndef BP_WIDE160_NB
+#define BP_WIDE160_NB 5
+#endif
+
+bool sense_wide_dma_takes(int s, int dk, int dout, bool vec_qk, bool vec_c, bool weighted) {
+#ifdef BP_WIDE_NO_DMA   // variant build for A/B runs: everything wide on the staged kernels of sense_wide.hip
+    return false;
+#endif
+    return vec_qk && vec_c && !weighted && (dk == 160 || dk == 640) && s % 32 == 0 && s > 0 && dout % 8 == 0;
+}
+
+template <class ET, int KD, int NW, int NB>
+static hipError_t launch_mix_wide_dma_cfg(const MixParams &p, hipStream_t stream) {
+    using C = WideDmaCfg<KD, NW, NB>;
+    const int n_qtiles = (p.s + C::BM - 1) / C::BM;
+    const int n_chunks = (p.dout + NB * 32 - 1) / (NB * 32);
+    const dim3 grid(xcd_grid(p.b * n_chunks, n_qtiles)), block(C::NT);
+    hipLaunchKernelGGL((sense_mix_wide_dma_kernel<ET, KD, NW, NB>), grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_sense_mix_wide_dma(const MixParams &p, int dtype, hipStream_t stream) {
+    if (p.dk == 160)
+        return dtype == 1 ? launch_mix_wide_dma_cfg<BF16, 10, BP_WIDE160_NW, BP_WIDE160_NB>(p, stream)
+                          : launch_mix_wide_dma_cfg<F16, 10, BP_WIDE160_NW, BP_WIDE160_NB>(p, stream);
+    return dtype == 1 ? launch_mix_wide_dma_cfg<BF16, 40, 4, 10>(p, stream)
+                      : launch_mix_wide_dma_cfg<F16, 40, 4, 10>(p, stream);
+}
+
+template <class ET, int KD, int NW>
+static hipError_t launch_lse_wide_dma_cfg(const MixParams &p, float *lse, hipStream_t stream) {
+    using C = WideDmaCfg<KD, NW, 0>;
+    const dim3 grid(xcd_grid(p.b * p.nsenses, (p.s + C::BM - 1) / C::BM)), block(C::NT);
+    hipLaunchKernelGGL((sense_lse_wide_dma_kernel<ET, KD, NW>), grid, block, 0, stream, p, lse);
+    return hipGetLastError();
+}
+
+hipError_t launch_sense_lse_wide_dma(const void *q, const void *k, float *lse, int64_t lse_stride, int64_t qk_bs,
+                                     int64_t qk_rs, int64_t qk_ss, int b, int s, int nsenses, int dk, float scale_log2e,
+                                     int dtype, hipStream_t stream) {
+    MixParams p{};
+    p.q = q; p.k = k; p.qk_bs = qk_bs; p.qk_rs = qk_rs; p.qk_ss = qk_ss;
+    p.lse_stride = lse_stride; p.b = b; p.s = s; p.nsenses = nsenses; p.dk = dk; p.scale_log2e = scale_log2e;
+    if (dk == 160)
+        return dtype == 1 ? launch_lse_wide_dma_cfg<BF16, 10, 8>(p, lse, stream)
+                          : launch_lse_wide_dma_cfg<F16, 10, 8>(p, lse, stream);
+    return dtype == 1 ? launch_lse_wide_dma_cfg<BF16, 40, 4>(p, lse, stream)
+                      : launch_lse_wide_dma_cfg<F16, 40, 4>(p, lse, stream);
+}
+
+}  // namespace bp
