@@ -108,6 +108,20 @@ BP_DEV u32x4 ld_global_8x2B(const uint16_t *row, int col0, int ncols) {
 BP_DEV void settle(u32x4 &v) { asm volatile("" : "+v"(v)); }
 BP_DEV void settle(float &v) { asm volatile("" : "+v"(v)); }
 
+// Drain the matrix pipe behind the last MFMA of a run whose results VECTOR instructions read next.  gfx950 does not interlock
+// "matrix pipe writes a VGPR -> VALU reads it": the compiler pads the gap with s_nop (11 issue slots for the 8-pass
+// 32x32x16), but hipcc / clang 22 (ROCm 7.2) only does so reliably INSIDE a basic block: with a branch between the MFMA and
+// its first reader -- a loop back-edge, the early exit of a run-time-bounded K loop -- the padding was found missing or short
+// (round 6: `v_max_f32 v59, v3, v3` one slot behind the v_mfma writing v[0:15] in sense_lse_wide_dma_kernel<.., 10, 8, 4>;
+// the stale register only moved a softmax reference maximum, i.e. the result by one ulp from launch to launch, found by a
+// repeatability probe).  An empty asm pin on the accumulator does not help (the hazard recognizer ignores inline asm
+// operands), so the wait is spelled out: 12 slots, in the MFMA's own block, tied to the accumulator so that neither the MFMA
+// nor its readers move across it.  `pin_acc` orders further accumulators of the same run behind the drain (volatile asm
+// statements keep their order).  scripts/mfma_hazard_scan.py checks every kernel of the library for early reads
+// (tests/test_code_objects.py).
+BP_DEV void settle_acc(f32x16 &v) { asm volatile("s_nop 7\n\ts_nop 3" : "+v"(v)); }
+BP_DEV void pin_acc(f32x16 &v) { asm volatile("" : "+v"(v)); }
+
 // Lane index recomputed on the spot (two VALU instructions) instead of being kept in a register from kernel entry: a
 // value every cold address computation needs is live across all the loops, and under register pressure hipcc spills
 // exactly such values -- the reload is a scratch load whose `s_waitcnt vmcnt(0)` also drains the LDS-DMA ring

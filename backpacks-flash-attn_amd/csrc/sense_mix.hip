@@ -172,6 +172,7 @@ __global__ __launch_bounds__(512) void sense_mix_kernel(const MixParams p) {
                 const u32x4 a = lds_read_16B(kbuf, k_lane_off + s * 32);
                 st = E::mfma(a, qf[s], st);
             }
+            settle_acc(st);   // wait for the matrix pipe in this block (bp_common.h)
             const bool diag = (kb == my_last_kb);
             const float *kw = p.kw != nullptr ? p.kw + batch * p.kw_bs + (int64_t)l * p.kw_ss : nullptr;
 #pragma unroll

@@ -105,6 +105,8 @@ BP_DEV f32x16 wide_scores(const char *kbuf, const u32x4 (&qf)[KDT], int kd, int 
             if (s & 1) st1 = E::mfma(a, qf[s], st1);
             else st0 = E::mfma(a, qf[s], st0);
         }
+    settle_acc(st1);   // the run-time bound `s < kd` puts a branch behind every MFMA: wait for the matrix pipe here (bp_common.h)
+    pin_acc(st0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) st0[r] += st1[r];
     return st0;

@@ -10,7 +10,9 @@
 // (registers -> LDS, one __syncthreads per key block, 128 output columns per workgroup: S^T recomputed five times for
 // d = 640, every MFMA behind its own LDS round trip):
 //   * the K rows and the content rows of a 32-key block reach LDS by DMA (`global_load_lds_dwordx4`, bp_dma.h) into a
-//     two-slot ring: block i + 1 is in flight while block i is multiplied; one s_barrier per block;
+//     ring of 2 to 4 slots: blocks i + 1 .. i + RING - 1 are in flight while block i is multiplied (with 0.6 us of MFMAs per
+//     block and ~2.4 us of DMA latency under load a two-slot ring waits for every block: d_k = 160 went 9.3 -> X ms at
+//     B = 1024 with four slots); counted vmcnt, one s_barrier per block;
 //   * a workgroup covers NB * 32 = 320 (or 160) output columns, so S^T and the exponentials are recomputed 2 (4) times per
 //     query block instead of 5;
 //   * the LDS operands of both MFMA runs are requested two MFMAs ahead (mfma_stream, bp_common.h);
@@ -23,7 +25,7 @@
 
 namespace bp {
 
-template <int KD, int NW, int NB>
+template <int KD, int NW, int NB, int RING = 2>
 struct WideDmaCfg {
     static constexpr int BK = 32;                      // keys per ring step
     static constexpr int NT = NW * 64;
@@ -36,9 +38,13 @@ struct WideDmaCfg {
     static constexpr int CROW = CSLOTS * 16;
     static constexpr int C_PIECES = BK * CSLOTS / 64;  // 2 NB (0 for the LSE kernel: K only)
     static constexpr int PIECES = K_PIECES + C_PIECES;
-    static constexpr int NPW = (PIECES + NW - 1) / NW; // DMA instructions per wave and step (the last wave may own fewer)
-    static constexpr int STAGE = PIECES * 1024;
-    static_assert(2 * STAGE <= 160 * 1024, "LDS budget");
+    static constexpr int NPW = (PIECES + NW - 1) / NW; // DMA instructions per wave and step: the SAME number for every wave, so
+    static constexpr int STAGE = NPW * NW * 1024;      // that `s_waitcnt vmcnt((RING - 2) NPW)` means "my share of the oldest
+                                                       // block in flight has landed" (pieces past PIECES re-fetch a K chunk
+                                                       // into the stage's unused tail)
+    static constexpr int WAIT = (RING - 2) * NPW;      // my pieces of the younger blocks that may still be in flight
+    static_assert(RING >= 2 && RING * STAGE <= 160 * 1024, "LDS budget");
+    static_assert(WAIT <= 63, "vmcnt is a 6-bit field");
 };
 
 // byte offset of (row, logical 16-byte chunk ch) in a content image of NB 64-byte chunks per row; ds_read_b64_tr_b16 serves
@@ -53,9 +59,9 @@ template <int NB> BP_DEV int wide_c_off(int row, int ch) {
 }
 
 // The ring: per-lane source offsets of my DMA pieces (constant over the sweep), and the issue of one step's pieces.
-template <int KD, int NW, int NB>
+template <int KD, int NW, int NB, int RING = 2>
 struct WideRing {
-    using C = WideDmaCfg<KD, NW, NB>;
+    using C = WideDmaCfg<KD, NW, NB, RING>;
     uint32_t voff[C::NPW];
     BP_DEV void setup(int wave, int lane, int64_t k_rs, int64_t c_rs, int col_base, int dout) {
 #pragma unroll
@@ -65,7 +71,7 @@ struct WideRing {
             const int krow = min(g / C::KSLOTS, C::BK - 1);   // region's tail re-fetch a valid chunk (never read)
             const int kch = min(g - (g / C::KSLOTS) * C::KSLOTS, 2 * KD - 1);
             uint32_t off = (uint32_t)(krow * k_rs + kch * 8) * 2u;
-            if constexpr (NB > 0) if (pi >= C::K_PIECES) {
+            if constexpr (NB > 0) if (pi >= C::K_PIECES && pi < C::PIECES) {
                 const int c = (pi - C::K_PIECES) * 64 + lane;
                 const int row = c / C::CSLOTS, stored = c - row * C::CSLOTS;
                 int c64 = stored >> 2;
@@ -81,15 +87,16 @@ struct WideRing {
 #pragma unroll
         for (int j = 0; j < C::NPW; ++j) {
             const int pi = wave * C::NPW + j;
-            if (pi < C::PIECES)
-                dma16_s((NB > 0 && pi >= C::K_PIECES) ? ct : kt, voff[j],
-                        __builtin_amdgcn_readfirstlane(stage + pi * 1024));
+            dma16_s((NB > 0 && pi >= C::K_PIECES && pi < C::PIECES) ? ct : kt, voff[j],
+                    __builtin_amdgcn_readfirstlane(stage + pi * 1024));
         }
     }
 };
 
 // S^T (32 keys x 32 queries) of the block in `kbuf`: two accumulation chains, operands two MFMAs ahead
-template <class ET, int KD, int KROW>
+// (TWO_CHAINS: with one wave per SIMD a single chain of dependent MFMAs leaves a bubble behind each; with two waves the
+// partner fills it and the second chain's 16 registers are better spent elsewhere)
+template <class ET, int KD, int KROW, bool TWO_CHAINS>
 BP_DEV f32x16 wide_dma_scores(const char *kbuf, const u32x4 (&qf)[KD], int l31, int hh) {
     using E = Elem<ET>;
     f32x16 st0, st1;
@@ -98,11 +105,17 @@ BP_DEV f32x16 wide_dma_scores(const char *kbuf, const u32x4 (&qf)[KD], int l31, 
     const int k_lane_off = l31 * KROW + hh * 16;
     mfma_stream<KD>([&](int i) { return lds_read_16B(kbuf, k_lane_off + i * 32); },
                     [&](int i, const u32x4 &a) {
-                        if (i & 1) st1 = E::mfma(a, qf[i], st1);
+                        if (TWO_CHAINS && (i & 1)) st1 = E::mfma(a, qf[i], st1);
                         else st0 = E::mfma(a, qf[i], st0);
                     });
+    if (TWO_CHAINS) {
+        settle_acc(st1);   // the wait for the matrix pipe belongs HERE, not behind whatever branch follows (bp_common.h)
+        pin_acc(st0);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) st0[r] += st1[r];
+        for (int r = 0; r < 16; ++r) st0[r] += st1[r];
+    } else {
+        settle_acc(st0);
+    }
     return st0;
 }
 
@@ -114,11 +127,11 @@ template <int KD> BP_DEV void wide_dma_load_q(u32x4 (&qf)[KD], const uint16_t *q
 }
 
 // ---- fused mix ---------------------------------------------------------------------------------------------------------
-template <class ET, int KD, int NW, int NB>
+template <class ET, int KD, int NW, int NB, int RING>
 __global__ __launch_bounds__(NW * 64) void sense_mix_wide_dma_kernel(const MixParams p) {
-    using C = WideDmaCfg<KD, NW, NB>;
+    using C = WideDmaCfg<KD, NW, NB, RING>;
     using E = Elem<ET>;
-    __shared__ __attribute__((aligned(16))) char smem[2 * C::STAGE];
+    __shared__ __attribute__((aligned(16))) char smem[RING * C::STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
     const int S = p.s;
@@ -142,14 +155,15 @@ __global__ __launch_bounds__(NW * 64) void sense_mix_wide_dma_kernel(const MixPa
     const float c2 = p.scale_log2e;
     const int nb_live = min(NB, (p.dout - col_base + 31) / 32);
 
-    WideRing<KD, NW, NB> ring;
+    WideRing<KD, NW, NB, RING> ring;
     ring.setup(wave, lane, p.qk_rs, p.c_rs, col_base, p.dout);
-    int l_i = 0, kb_i = 0;                            // (sense, key block) of the next issue
-    auto issue = [&](int step) {
+    int l_i = 0, kb_i = 0, slot_i = 0;                // (sense, key block) and ring slot of the next issue
+    auto issue = [&]() {
         const uint16_t *kt = kg + (int64_t)l_i * p.qk_ss + (int64_t)kb_i * C::BK * p.qk_rs;
         const uint16_t *ct = cg + (int64_t)l_i * p.c_ss + (int64_t)kb_i * C::BK * p.c_rs;
-        ring.issue(wave, lds0 + (step & 1) * C::STAGE, kt, ct);
+        ring.issue(wave, lds0 + slot_i * C::STAGE, kt, ct);
         if (++kb_i == nkb) { kb_i = 0; ++l_i; }
+        if (++slot_i == RING) slot_i = 0;
     };
 
     f32x16 acc[NB];
@@ -171,22 +185,27 @@ __global__ __launch_bounds__(NW * 64) void sense_mix_wide_dma_kernel(const MixPa
     float lse2 = 0.f;
     const uint16_t *qrow = qg + (int64_t)min(my_q, S - 1) * p.qk_rs;
 
-    issue(0);
+    for (int t = 0; t < RING - 1 && t < nsteps; ++t) issue();
+    int slot_r = 0;                        // ring slot of this step's block
     for (int step = 0; step < nsteps; ++step) {
         const int l = step / nkb, kb = step - l * nkb;
-        wait_vmcnt<0>();                   // my pieces of this step's block have landed ...
-        __builtin_amdgcn_s_barrier();      // ... so have everybody's; nobody reads the other slot any more
-        if (kb == 0 && wave_has_rows) {    // a new sense: my row's fragments and log-sum-exp (before the next DMA is in flight:
-                                           // the compiler's wait for them must not drain the ring)
+        // my pieces of this step's block have landed (RING - 2 younger blocks may stay in flight; in the sweep's last steps
+        // there are fewer of them: wait for all) ...
+        if (RING > 2 && step + RING - 2 < nsteps) wait_vmcnt<C::WAIT>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();      // ... so have everybody's; nobody reads the slot of the previous step any more
+        if (kb == 0 && wave_has_rows) {    // a new sense: my row's fragments and log-sum-exp (the compiler's wait for these
+                                           // loads also waits for the DMA in flight: once per sense)
             wide_dma_load_q<KD>(qf, qrow + (int64_t)l * p.qk_ss, hh);
             lse2 = p.lse[((int64_t)batch * p.nsenses + l) * p.lse_stride + my_q] * kLog2e;
             settle(lse2);
         }
-        if (step + 1 < nsteps) issue(step + 1);
+        if (step + RING - 1 < nsteps) issue();
+        const char *kbuf = smem + slot_r * C::STAGE;
+        if (++slot_r == RING) slot_r = 0;
         if (wave_has_rows && kb <= my_last_kb) {
-            const char *kbuf = smem + (step & 1) * C::STAGE;
             const char *cbuf = kbuf + C::KREGION;
-            f32x16 st = wide_dma_scores<ET, KD, C::KROW>(kbuf, qf, l31, hh);
+            f32x16 st = wide_dma_scores<ET, KD, C::KROW, (NW <= 4)>(kbuf, qf, l31, hh);
             u32x4 pf[2];
             if (kb == my_last_kb) {        // the diagonal block: exact zeros above the diagonal
                 const int lim = l31 - 4 * hh;   // my_q - kb * 32 - 4 hh
@@ -225,6 +244,9 @@ __global__ __launch_bounds__(NW * 64) void sense_mix_wide_dma_kernel(const MixPa
     }
 
     if (!wave_has_rows) return;
+    settle_acc(acc[NB - 1]);   // (the loop's exit branch separates the last MFMAs from the stores)
+#pragma unroll
+    for (int n = 0; n < NB - 1; ++n) pin_acc(acc[n]);
     uint16_t *og = reinterpret_cast<uint16_t *>(p.o) + batch * p.o_bs + (int64_t)my_q * p.o_rs;
 #pragma unroll
     for (int n = 0; n < NB; ++n)
@@ -239,10 +261,10 @@ __global__ __launch_bounds__(NW * 64) void sense_mix_wide_dma_kernel(const MixPa
 }
 
 // ---- LSE ---------------------------------------------------------------------------------------------------------------
-template <class ET, int KD, int NW>
+template <class ET, int KD, int NW, int RING>
 __global__ __launch_bounds__(NW * 64) void sense_lse_wide_dma_kernel(const MixParams p, float *lse_out) {
-    using C = WideDmaCfg<KD, NW, 0>;
-    __shared__ __attribute__((aligned(16))) char smem[2 * C::STAGE];
+    using C = WideDmaCfg<KD, NW, 0, RING>;
+    __shared__ __attribute__((aligned(16))) char smem[RING * C::STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
     const int S = p.s;
@@ -261,19 +283,32 @@ __global__ __launch_bounds__(NW * 64) void sense_lse_wide_dma_kernel(const MixPa
     const int my_last_kb = q0 / C::BK;
     const float c2 = p.scale_log2e;
 
-    WideRing<KD, NW, 0> ring;
+    WideRing<KD, NW, 0, RING> ring;
     ring.setup(wave, lane, p.qk_rs, 0, 0, 0);
     u32x4 qf[KD];
     if (wave_has_rows) wide_dma_load_q<KD>(qf, qg + (int64_t)min(my_q, S - 1) * p.qk_rs, hh);
     float m_run = -INFINITY, l_run = 0.f;
-    ring.issue(wave, lds0, kg, kg);
+    int kb_i = 0, slot_i = 0, slot_r = 0;
+    auto issue = [&]() {
+        const uint16_t *kt = kg + (int64_t)kb_i * C::BK * p.qk_rs;
+        ring.issue(wave, lds0 + slot_i * C::STAGE, kt, kt);
+        ++kb_i;
+        if (++slot_i == RING) slot_i = 0;
+    };
+    for (int t = 0; t < RING - 1 && t < nkb; ++t) issue();
     for (int kb = 0; kb < nkb; ++kb) {
+#ifdef BP_WIDE_WAIT_ALL   // probe build: deeper ring, but every wait drains it
         wait_vmcnt<0>();
+#else
+        if (RING > 2 && kb + RING - 2 < nkb) wait_vmcnt<C::WAIT>();
+        else wait_vmcnt<0>();
+#endif
         __builtin_amdgcn_s_barrier();
-        if (kb + 1 < nkb)
-            ring.issue(wave, lds0 + ((kb + 1) & 1) * C::STAGE, kg + (int64_t)(kb + 1) * C::BK * p.qk_rs, kg);
+        if (kb + RING - 1 < nkb) issue();
+        const char *kbuf = smem + slot_r * C::STAGE;
+        if (++slot_r == RING) slot_r = 0;
         if (wave_has_rows && kb <= my_last_kb) {
-            f32x16 st = wide_dma_scores<ET, KD, C::KROW>(smem + (kb & 1) * C::STAGE, qf, l31, hh);
+            f32x16 st = wide_dma_scores<ET, KD, C::KROW, (NW <= 4)>(kbuf, qf, l31, hh);
             if (kb == my_last_kb) {
                 const int lim = l31 - 4 * hh;
 #pragma unroll
@@ -311,7 +346,16 @@ __global__ __launch_bounds__(NW * 64) void sense_lse_wide_dma_kernel(const MixPa
 #define BP_WIDE160_NW 8
 #endif
 #ifndef BP_WIDE160_NB
-#define BP_WIDE160_NB 5
+#define BP_WIDE160_NB 10
+#endif
+#ifndef BP_WIDE160_RING
+#define BP_WIDE160_RING 2
+#endif
+#ifndef BP_WIDE160_LSE_RING
+#define BP_WIDE160_LSE_RING 2
+#endif
+#ifndef BP_WIDE640_LSE_RING
+#define BP_WIDE640_LSE_RING 2
 #endif
 
 bool sense_wide_dma_takes(int s, int dk, int dout, bool vec_qk, bool vec_c, bool weighted) {
@@ -321,29 +365,29 @@ bool sense_wide_dma_takes(int s, int dk, int dout, bool vec_qk, bool vec_c, bool
     return vec_qk && vec_c && !weighted && (dk == 160 || dk == 640) && s % 32 == 0 && s > 0 && dout % 8 == 0;
 }
 
-template <class ET, int KD, int NW, int NB>
+template <class ET, int KD, int NW, int NB, int RING>
 static hipError_t launch_mix_wide_dma_cfg(const MixParams &p, hipStream_t stream) {
-    using C = WideDmaCfg<KD, NW, NB>;
+    using C = WideDmaCfg<KD, NW, NB, RING>;
     const int n_qtiles = (p.s + C::BM - 1) / C::BM;
     const int n_chunks = (p.dout + NB * 32 - 1) / (NB * 32);
     const dim3 grid(xcd_grid(p.b * n_chunks, n_qtiles)), block(C::NT);
-    hipLaunchKernelGGL((sense_mix_wide_dma_kernel<ET, KD, NW, NB>), grid, block, 0, stream, p);
+    hipLaunchKernelGGL((sense_mix_wide_dma_kernel<ET, KD, NW, NB, RING>), grid, block, 0, stream, p);
     return hipGetLastError();
 }
 
 hipError_t launch_sense_mix_wide_dma(const MixParams &p, int dtype, hipStream_t stream) {
     if (p.dk == 160)
-        return dtype == 1 ? launch_mix_wide_dma_cfg<BF16, 10, BP_WIDE160_NW, BP_WIDE160_NB>(p, stream)
-                          : launch_mix_wide_dma_cfg<F16, 10, BP_WIDE160_NW, BP_WIDE160_NB>(p, stream);
-    return dtype == 1 ? launch_mix_wide_dma_cfg<BF16, 40, 4, 10>(p, stream)
-                      : launch_mix_wide_dma_cfg<F16, 40, 4, 10>(p, stream);
+        return dtype == 1 ? launch_mix_wide_dma_cfg<BF16, 10, BP_WIDE160_NW, BP_WIDE160_NB, BP_WIDE160_RING>(p, stream)
+                          : launch_mix_wide_dma_cfg<F16, 10, BP_WIDE160_NW, BP_WIDE160_NB, BP_WIDE160_RING>(p, stream);
+    return dtype == 1 ? launch_mix_wide_dma_cfg<BF16, 40, 4, 10, 2>(p, stream)
+                      : launch_mix_wide_dma_cfg<F16, 40, 4, 10, 2>(p, stream);
 }
 
-template <class ET, int KD, int NW>
+template <class ET, int KD, int NW, int RING>
 static hipError_t launch_lse_wide_dma_cfg(const MixParams &p, float *lse, hipStream_t stream) {
-    using C = WideDmaCfg<KD, NW, 0>;
+    using C = WideDmaCfg<KD, NW, 0, RING>;
     const dim3 grid(xcd_grid(p.b * p.nsenses, (p.s + C::BM - 1) / C::BM)), block(C::NT);
-    hipLaunchKernelGGL((sense_lse_wide_dma_kernel<ET, KD, NW>), grid, block, 0, stream, p, lse);
+    hipLaunchKernelGGL((sense_lse_wide_dma_kernel<ET, KD, NW, RING>), grid, block, 0, stream, p, lse);
     return hipGetLastError();
 }
 
@@ -354,10 +398,10 @@ hipError_t launch_sense_lse_wide_dma(const void *q, const void *k, float *lse, i
     p.q = q; p.k = k; p.qk_bs = qk_bs; p.qk_rs = qk_rs; p.qk_ss = qk_ss;
     p.lse_stride = lse_stride; p.b = b; p.s = s; p.nsenses = nsenses; p.dk = dk; p.scale_log2e = scale_log2e;
     if (dk == 160)
-        return dtype == 1 ? launch_lse_wide_dma_cfg<BF16, 10, 8>(p, lse, stream)
-                          : launch_lse_wide_dma_cfg<F16, 10, 8>(p, lse, stream);
-    return dtype == 1 ? launch_lse_wide_dma_cfg<BF16, 40, 4>(p, lse, stream)
-                      : launch_lse_wide_dma_cfg<F16, 40, 4>(p, lse, stream);
+        return dtype == 1 ? launch_lse_wide_dma_cfg<BF16, 10, 8, BP_WIDE160_LSE_RING>(p, lse, stream)
+                          : launch_lse_wide_dma_cfg<F16, 10, 8, BP_WIDE160_LSE_RING>(p, lse, stream);
+    return dtype == 1 ? launch_lse_wide_dma_cfg<BF16, 40, 4, BP_WIDE640_LSE_RING>(p, lse, stream)
+                      : launch_lse_wide_dma_cfg<F16, 40, 4, BP_WIDE640_LSE_RING>(p, lse, stream);
 }
 
 }  // namespace bp

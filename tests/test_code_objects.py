@@ -46,6 +46,12 @@ HOT = [
     ('sense_wide.o', 'sense_mix_wide_kernel<BF16, true, true, 40>', 1),
     ('sense_wide.o', 'sense_lse_wide_kernel<BF16, true, 12>', 3),
     ('sense_wide.o', 'sense_lse_wide_kernel<BF16, true, 40>', 1),
+    # the same two configurations on the LDS-DMA ring (sense_wide_dma.hip): d_k = 160 as eight waves x 320 columns at two
+    # waves per SIMD, d_k = 640 as four waves x 320 columns owning the file
+    ('sense_wide_dma.o', 'sense_mix_wide_dma_kernel<BF16, 10, 8, 10, 2>', 2),
+    ('sense_wide_dma.o', 'sense_mix_wide_dma_kernel<BF16, 40, 4, 10, 2>', 1),
+    ('sense_wide_dma.o', 'sense_lse_wide_dma_kernel<BF16, 10, 8, 2>', 4),
+    ('sense_wide_dma.o', 'sense_lse_wide_dma_kernel<BF16, 40, 4, 2>', 2),
 ]
 
 
@@ -80,7 +86,23 @@ def test_resource_table_lists_every_object(table):
     assert all('vgpr_count' in k and 'sgpr_spill_count' in k for k in table.values())
 
 
-@pytest.mark.parametrize('obj', ['flash_fwd_dma.o', 'flash_bwd.o', 'sense_mix_dma.o', 'sense_mix_bwd.o'])
+def test_no_vector_instruction_reads_an_mfma_result_early(table):
+    """gfx950 does not interlock "matrix pipe writes a VGPR -> VALU reads it"; hipcc pads the gap with s_nop, but not
+    reliably across a branch (csrc/bp_common.h, settle_acc: found in round 6 as a one-ulp launch-to-launch variation of the
+    wide LSE kernel).  scripts/mfma_hazard_scan.py walks every path behind every v_mfma of every kernel of the library;
+    nothing may name a destination register of the MFMA before its wait states are over."""
+    import mfma_hazard_scan as HS
+    if not os.path.exists(os.path.join(KR.LLVM, 'llvm-objdump')):
+        pytest.skip('llvm-objdump not found under /opt/rocm')
+    hits = []
+    import glob
+    for obj in sorted(glob.glob(os.path.join(KR.BUILD, '*.o'))):
+        for name, ins in HS.functions(HS.disassemble(obj)):
+            hits += HS.scan(name, ins)
+    assert not hits, hits[:5]
+
+
+@pytest.mark.parametrize('obj', ['flash_fwd_dma.o', 'flash_bwd.o', 'sense_mix_dma.o', 'sense_mix_bwd.o', 'sense_wide_dma.o'])
 def test_no_instruction_reads_m0_besides_the_lds_dma(obj):
     """csrc/bp_dma.h: `dma16_s` writes M0 and names it as clobbered instead of saving and restoring it (two scalar moves per
     1-KiB piece less).  That is only sound while no compiler-generated instruction in these kernels READS M0 -- relative
