@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('BP_HIP_LIB') or os.path.join(_HERE, 'libbackpack_hip.so')  # env: A/B builds only
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _lib = None
 
@@ -437,24 +437,41 @@ def sense_mix(qk, content, softmax_scale=None, out=None, lse=None, key_weight=No
 SENSE_MAX_DK = 640     # widest sense bp_sense_lse / _alpha / _mix take (include/bp_hip.h; > 128: csrc/sense_wide.hip)
 
 
+WIDE_RING_DK = (160, 640)   # sense widths beyond 128 the LDS-DMA ring kernels take (csrc/sense_wide_dma.hip), with S % 32 == 0
+
+
+def _wide_ring_takes(dk, seqlen):
+    return dk in WIDE_RING_DK and seqlen % 32 == 0
+
+
 def sense_mix_gather_supported(qk, table, seqlen):
-    """Shapes bp_sense_mix_gather takes (include/bp_hip.h): the 16-byte vector path, seqlen <= 4096, at most 65 536 table
-    rows (any GPT-2 vocabulary), 32-bit byte offsets into the table."""
+    """Shapes bp_sense_mix_gather takes (include/bp_hip.h): the 16-byte vector path, seqlen <= 4096, 32-bit byte offsets into
+    the table; senses up to 128 wide with at most 65 536 table rows (any GPT-2 vocabulary), or the reference's two few-sense
+    widths (160 / 640, seqlen a multiple of 32: the ring kernels of csrc/sense_wide_dma.hip, any row count)."""
     dk = round_up(qk.shape[-1], 8)
-    return (dk <= 128 and qk.is_cuda and table.is_cuda and table.dim() == 3 and table.stride(-1) == 1 and table.shape[2] % 8 == 0
+    wide = dk > 128
+    return ((dk <= 128 or _wide_ring_takes(dk, seqlen)) and qk.is_cuda and table.is_cuda and table.dim() == 3
+            and table.stride(-1) == 1 and table.shape[2] % 8 == 0
             and table.stride(0) % 8 == 0 and table.stride(1) % 8 == 0 and table.data_ptr() % 16 == 0
-            and seqlen <= 4096 and table.shape[0] <= 65536
+            and seqlen <= 4096 and (wide or table.shape[0] <= 65536)
+            and (not wide or _vector_friendly_strides(qk))
             and table.shape[0] * table.stride(0) * table.element_size() < 2 ** 32)
+
+
+def _vector_friendly_strides(qk):
+    return qk.data_ptr() % 16 == 0 and all(st % 8 == 0 for st in qk.stride()[:4])
 
 
 def sense_mix_gather_limits(qk, table, seqlen):
     """Which limit of bp_sense_mix_gather a call exceeds, as text (callers log it when they fall back to a torch gather)."""
     why = []
-    if round_up(qk.shape[-1], 8) > 128:
-        why.append(f'sense width {qk.shape[-1]} > 128 (wide senses take the dense kernel)')
+    dk = round_up(qk.shape[-1], 8)
+    if dk > 128 and not _wide_ring_takes(dk, seqlen):
+        why.append(f'sense width {qk.shape[-1]} > 128 and not {WIDE_RING_DK} at a sequence length that is a multiple of 32 '
+                   '(those senses take the dense kernel)')
     if seqlen > 4096:
         why.append(f'sequence length {seqlen} > 4096 (a job keeps its keys\' row indices in LDS)')
-    if table.shape[0] > 65536:
+    if table.shape[0] > 65536 and dk <= 128:
         why.append(f'{table.shape[0]} table rows > 65536 (u16 row indices)')
     if table.shape[0] * table.stride(0) * table.element_size() >= 2 ** 32:
         why.append('table of 4 GiB or more (32-bit byte offsets)')

@@ -367,10 +367,14 @@ int bp_sense_mix_gather(const void *qk, const void *table, const int32_t *row_in
                         int64_t o_batch_stride, int64_t o_row_stride,
                         float softmax_scale, int dtype, void *queue_ws, bp_stream_t stream) {
     if (dtype != BP_DTYPE_F16 && dtype != BP_DTYPE_BF16) return BP_ERR_DTYPE;
-    if (d_k < 8 || d_k > 128 || d_k % 8 != 0) return BP_ERR_HEAD_DIM;
+    // wide senses: the reference's two few-sense widths on the ring kernels of sense_wide_dma.hip (row indices as u32 in LDS:
+    // no limit on the row count); everything else wider than 128 is gathered by the caller
+    const bool wide = d_k > 128 && bp::sense_wide_dma_takes(seqlen, d_k, d_out, true, true, false);
+    if (d_k < 8 || (d_k > 128 && !wide) || d_k % 8 != 0) return BP_ERR_HEAD_DIM;
     if (queue_ws != nullptr && !aligned16(queue_ws)) return BP_ERR_SHAPE;
     if (d_out < 8 || d_out % 8 != 0) return BP_ERR_DOUT;
-    if (batch <= 0 || nsenses <= 0 || seqlen <= 0 || seqlen > bp::kMixGatherMaxKeys || table_rows <= 0 || table_rows > bp::kMixGatherMaxRows) return BP_ERR_SHAPE;
+    if (batch <= 0 || nsenses <= 0 || seqlen <= 0 || seqlen > bp::kMixGatherMaxKeys || table_rows <= 0 ||
+        (!wide && table_rows > bp::kMixGatherMaxRows)) return BP_ERR_SHAPE;
     if (qk == nullptr || table == nullptr || row_index == nullptr || out == nullptr || lse_ws == nullptr) return BP_ERR_SHAPE;
     if (!scale_ok(softmax_scale)) return BP_ERR_SCALE;
     const uint16_t *qp = static_cast<const uint16_t *>(qk);
@@ -398,7 +402,7 @@ int bp_sense_mix_gather(const void *qk, const void *table, const int32_t *row_in
     p.n_chunks = (d_out + 255) / 256;
     p.scale_log2e = softmax_scale * bp::kLog2e;
     p.queues = static_cast<bp::MixQueues *>(queue_ws);
-    const hipError_t e = bp::launch_sense_mix_dma(p, dtype, st);
+    const hipError_t e = wide ? bp::launch_sense_mix_wide_dma(p, dtype, st) : bp::launch_sense_mix_dma(p, dtype, st);
     return e == hipSuccess ? BP_OK : BP_ERR_LAUNCH;
 }
 

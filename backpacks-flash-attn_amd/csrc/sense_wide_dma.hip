@@ -63,7 +63,10 @@ template <int KD, int NW, int NB, int RING = 2>
 struct WideRing {
     using C = WideDmaCfg<KD, NW, NB, RING>;
     uint32_t voff[C::NPW];
-    BP_DEV void setup(int wave, int lane, int64_t k_rs, int64_t c_rs, int col_base, int dout) {
+    // GATHER: the content rows are rows of a table picked by an index per key (bp_sense_mix_gather).  A content piece's
+    // descriptor is then (row of the block) << 16 | byte offset of its column inside the chunk; the table row's byte offset
+    // (index * row bytes, 32-bit: tables below 4 GiB) is added per step from the workgroup's index array in LDS.
+    BP_DEV void setup(int wave, int lane, int64_t k_rs, int64_t c_rs, int col_base, int dout, bool gather = false) {
 #pragma unroll
         for (int j = 0; j < C::NPW; ++j) {
             const int pi = wave * C::NPW + j;
@@ -78,7 +81,8 @@ struct WideRing {
                 if (NB == 10) c64 ^= (row >> 1) & 1;
                 int col = col_base + ((c64 << 2) | (stored & 3)) * 8;
                 if (col >= dout) col = col_base;              // columns past d_out: any finite data (never stored)
-                off = (uint32_t)(row * c_rs + col) * 2u;
+                off = gather ? ((uint32_t)row << 16) | (uint32_t)((col - col_base) * 2)
+                             : (uint32_t)(row * c_rs + col) * 2u;
             }
             voff[j] = off;
         }
@@ -89,6 +93,21 @@ struct WideRing {
             const int pi = wave * C::NPW + j;
             dma16_s((NB > 0 && pi >= C::K_PIECES && pi < C::PIECES) ? ct : kt, voff[j],
                     __builtin_amdgcn_readfirstlane(stage + pi * 1024));
+        }
+    }
+    // ids: the workgroup's row indices (uint32, already clamped to the table) of key 0, 1, ... in LDS; key0: first key of the block
+    BP_DEV void issue_gather(int wave, uint32_t stage, const uint16_t *kt, const uint16_t *ct, const char *ids, int key0,
+                             uint32_t row_bytes) const {
+#pragma unroll
+        for (int j = 0; j < C::NPW; ++j) {
+            const int pi = wave * C::NPW + j;
+            const bool content = NB > 0 && pi >= C::K_PIECES && pi < C::PIECES;   // wave-uniform
+            uint32_t off = voff[j];
+            if (content) {
+                const uint32_t id = *reinterpret_cast<const uint32_t *>(ids + (key0 + (int)(off >> 16)) * 4);
+                off = id * row_bytes + (off & 0xffffu);
+            }
+            dma16_s(content ? ct : kt, off, __builtin_amdgcn_readfirstlane(stage + pi * 1024));
         }
     }
 };
@@ -127,11 +146,13 @@ template <int KD> BP_DEV void wide_dma_load_q(u32x4 (&qf)[KD], const uint16_t *q
 }
 
 // ---- fused mix ---------------------------------------------------------------------------------------------------------
-template <class ET, int KD, int NW, int NB, int RING>
+template <class ET, int KD, int NW, int NB, int RING, bool GATHER>
 __global__ __launch_bounds__(NW * 64) void sense_mix_wide_dma_kernel(const MixParams p) {
     using C = WideDmaCfg<KD, NW, NB, RING>;
     using E = Elem<ET>;
-    __shared__ __attribute__((aligned(16))) char smem[RING * C::STAGE];
+    constexpr int kIdsOff = RING * C::STAGE;           // GATHER: the job's row indices behind the ring, 4 bytes per key
+    static_assert(!GATHER || kIdsOff + kMixGatherMaxKeys * 4 <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) char smem[kIdsOff + (GATHER ? kMixGatherMaxKeys * 4 : 0)];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
     const int S = p.s;
@@ -145,10 +166,16 @@ __global__ __launch_bounds__(NW * 64) void sense_mix_wide_dma_kernel(const MixPa
     const int col_base = chunk * NB * 32;
     const uint16_t *qg = reinterpret_cast<const uint16_t *>(p.q) + batch * p.qk_bs;
     const uint16_t *kg = reinterpret_cast<const uint16_t *>(p.k) + batch * p.qk_bs;
-    const uint16_t *cg = reinterpret_cast<const uint16_t *>(p.c) + batch * p.c_bs;
+    const uint16_t *cg = reinterpret_cast<const uint16_t *>(p.c) + batch * p.c_bs;   // (GATHER: the table, c_bs = 0)
     const int k_end = min(S, qt * C::BM + C::BM);
     const int nkb = k_end / C::BK;                    // S % 32 == 0 (launcher)
     const int nsteps = p.nsenses * nkb;
+    if (GATHER) {   // my keys' table rows, clamped as unsigned values (a negative or too large index reads the LAST row)
+        const int32_t *idx = p.row_index + batch * p.idx_bs;
+        for (int i = tid; i < k_end; i += C::NT)
+            *reinterpret_cast<uint32_t *>(smem + kIdsOff + i * 4) = min((uint32_t)idx[i], p.last_table_row);
+        __syncthreads();
+    }
     const int q0 = qt * C::BM + wave * 32, my_q = q0 + l31;
     const bool wave_has_rows = q0 < S;                // then every row of the wave exists
     const int my_last_kb = q0 / C::BK;
@@ -156,12 +183,17 @@ __global__ __launch_bounds__(NW * 64) void sense_mix_wide_dma_kernel(const MixPa
     const int nb_live = min(NB, (p.dout - col_base + 31) / 32);
 
     WideRing<KD, NW, NB, RING> ring;
-    ring.setup(wave, lane, p.qk_rs, p.c_rs, col_base, p.dout);
+    ring.setup(wave, lane, p.qk_rs, p.c_rs, col_base, p.dout, GATHER);
     int l_i = 0, kb_i = 0, slot_i = 0;                // (sense, key block) and ring slot of the next issue
     auto issue = [&]() {
         const uint16_t *kt = kg + (int64_t)l_i * p.qk_ss + (int64_t)kb_i * C::BK * p.qk_rs;
-        const uint16_t *ct = cg + (int64_t)l_i * p.c_ss + (int64_t)kb_i * C::BK * p.c_rs;
-        ring.issue(wave, lds0 + slot_i * C::STAGE, kt, ct);
+        if (GATHER) {
+            ring.issue_gather(wave, lds0 + slot_i * C::STAGE, kt, cg + (int64_t)l_i * p.c_ss + col_base, smem + kIdsOff,
+                              kb_i * C::BK, (uint32_t)p.c_rs * 2u);
+        } else {
+            const uint16_t *ct = cg + (int64_t)l_i * p.c_ss + (int64_t)kb_i * C::BK * p.c_rs;
+            ring.issue(wave, lds0 + slot_i * C::STAGE, kt, ct);
+        }
         if (++kb_i == nkb) { kb_i = 0; ++l_i; }
         if (++slot_i == RING) slot_i = 0;
     };
@@ -371,7 +403,10 @@ static hipError_t launch_mix_wide_dma_cfg(const MixParams &p, hipStream_t stream
     const int n_qtiles = (p.s + C::BM - 1) / C::BM;
     const int n_chunks = (p.dout + NB * 32 - 1) / (NB * 32);
     const dim3 grid(xcd_grid(p.b * n_chunks, n_qtiles)), block(C::NT);
-    hipLaunchKernelGGL((sense_mix_wide_dma_kernel<ET, KD, NW, NB, RING>), grid, block, 0, stream, p);
+    if (p.row_index != nullptr)
+        hipLaunchKernelGGL((sense_mix_wide_dma_kernel<ET, KD, NW, NB, RING, true>), grid, block, 0, stream, p);
+    else
+        hipLaunchKernelGGL((sense_mix_wide_dma_kernel<ET, KD, NW, NB, RING, false>), grid, block, 0, stream, p);
     return hipGetLastError();
 }
 

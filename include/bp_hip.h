@@ -28,14 +28,16 @@
 extern "C" {
 #endif
 
-#define BP_ABI_VERSION 8   /* 2: *_dropout entry points added; 3: bias/GELU + column-sum entry points added, the
+#define BP_ABI_VERSION 9   /* 2: *_dropout entry points added; 3: bias/GELU + column-sum entry points added, the
                               persistent sense-mix launches take a caller-owned `queue_ws`; 4: bp_flash_bwd* take the
                               size of `dsum_ws` (bp_flash_bwd_ws_floats) and check it, queue_ws == NULL is refused
                               while the stream is capturing (BP_ERR_QUEUE_WS); 5: bp_dropout_add_layer_norm_scaled{,_bwd}
                               (rowscale / colscale of the reference's dropout_add_ln) added; 6: bp_sense_mix_gather added;
                               7: bp_sense_mix_gather clamps row_index to the table and takes tables of at most 65 536 rows;
                               8: bp_sense_lse / _alpha / _mix / _mix_weighted take sense widths d_k up to 640 (wide senses:
-                              the reference's vecs-4 / vecs-1 ablations), bp_build_flags() added */
+                              the reference's vecs-4 / vecs-1 ablations), bp_build_flags() added;
+                              9: bp_sense_mix_gather takes the two few-sense widths d_k = 160 / 640 (seqlen % 32 == 0; any
+                              number of table rows) */
 
 /* element type of q/k/v/out/content tensors */
 #define BP_DTYPE_F16 0
@@ -158,7 +160,9 @@ int bp_attn_probs_dropout(const void *q, const void *k, const float *softmax_lse
  * attention-class kernels run (LDS-DMA path for 16-byte friendly layouts); 129 ... 640 -- the reference's few-sense
  * ablations, training/configs/experiment/owt/backpack-mini-flash-vecs-4.yaml (d_k = 160) and ...-vecs-1.yaml (640) --
  * the wide kernels of csrc/sense_wide.hip (any alignment; d_k % 8 == 0 with 16-byte aligned rows takes 16-byte loads).
- * bp_sense_mix_gather and the backward entry points stay at d_k <= 128.
+ * At d_k = 160 / 640 exactly, on 16-byte friendly operands with seqlen % 32 == 0, the LDS-DMA ring kernels of
+ * csrc/sense_wide_dma.hip run instead (bp_sense_lse, bp_sense_mix; bp_sense_mix_gather takes only these two widths beyond 128).
+ * The backward entry points stay at d_k <= 128.
  */
 int bp_sense_lse(const void *qk, float *lse, int batch, int seqlen, int nsenses, int d_k,
                  int64_t qk_batch_stride, int64_t qk_row_stride, int64_t qk_two_stride,
@@ -241,7 +245,8 @@ int bp_sense_mix_weighted(const void *qk, const void *content, const float *key_
  * Restrictions (BP_ERR_SHAPE otherwise; callers gather the rows themselves and call bp_sense_mix): the 16-byte vector
  * path (d_k % 8 == 0, d_out % 8 == 0, aligned bases, strides multiples of 8), seqlen <= 4096 and table_rows <= 65536 (a
  * job's row indices are kept in 8 KB of LDS as u16; ABI 6 took any row count at seqlen <= 4096 / 2048), and
- * table_rows * t_row_stride * 2 bytes < 4 GiB (row offsets are 32-bit in the DMA instruction).
+ * table_rows * t_row_stride * 2 bytes < 4 GiB (row offsets are 32-bit in the DMA instruction).  Senses wider than 128:
+ * d_k = 160 or 640 with seqlen % 32 == 0 only (ABI 9; row indices are kept as u32, any table_rows); BP_ERR_HEAD_DIM otherwise.
  * All other arguments as bp_sense_mix.
  */
 int bp_sense_mix_gather(const void *qk, const void *table, const int32_t *row_index, void *out,

@@ -1,7 +1,7 @@
 """Micro-benchmark of the individual HIP kernels on synthetic N(0,1) data (never zeros: zero-filled
 inputs clock higher and flatter -- cdna_hip_programming.md section 5.4 rule 25).
 
-    python scripts/bench_kernels.py [--which flash,bwd,mix,lse,alpha,mixbwd,lnbwd,xent,gelu] [--batch 64] [--seq 1024] [--iters 20]
+    python scripts/bench_kernels.py [--which flash,bwd,mix,mixgather,mixgatherref,lse,alpha,mixbwd,lnbwd,xent,gelu] [--batch 64] [--seq 1024] [--iters 20]
 Prints one JSON line per kernel with avg ms, algorithmic TFLOP/s and GB/s (SURVEY section 8d figures)."""
 import argparse
 import json
@@ -102,6 +102,15 @@ def main():
         by = (4 * S * d + 2 * S * d + 4 * S) * B + 2 * rows * K * d
         res.append(dict(kernel='sense_mix_gather', ms=ms, tflops=2 * pairs * d * (1 + K) * B / ms / 1e9, gbps=by / ms / 1e6,
                         algorithmic_bytes=by))
+    if 'mixgatherref' in which:
+        # what the table form replaces when the kernel does not gather: torch gathers the (B,S,k,d) rows, then bp_sense_mix
+        rows = int(os.environ.get('BP_BENCH_TABLE_ROWS', '50257'))
+        table = torch.randn(rows, K, d, device=dev).to(dt)
+        index = torch.randint(0, rows, (B, S), device=dev, dtype=torch.int64)
+        lse = bp_hip.sense_lse(qk)
+        out = torch.empty(B, S, d, device=dev, dtype=dt)
+        ms = timeit(lambda: bp_hip.sense_mix(qk, table[index], out=out, lse=lse), a.iters)
+        res.append(dict(kernel='torch_gather+sense_mix', ms=ms, tflops=2 * pairs * d * (1 + K) * B / ms / 1e9))
     if 'alpha' in which:
         Ba = min(B, 64)     # (Ba, k, S, S) 16-bit: 2.1 GB at 64 x 16 x 1024^2 -- far past the 256 MiB Infinity Cache
         lse = bp_hip.sense_lse(qk[:Ba])

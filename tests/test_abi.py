@@ -70,9 +70,14 @@ def test_argument_validation_returns_before_any_launch():
     assert h.bp_flash_fwd_dropout(p, p, null, null, p, null, null, *tail, 0.1, p, null) == -7
     # sense mix: d_out < 1, d_k out of range
     assert h.bp_sense_mix(p, p, p, p, 0, 1, 16, 4, 16, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0.25, 1, null, null) == -6
-    # (sense widths up to 640 are taken since ABI 8 -- csrc/sense_wide.hip; the gathering form stays at 128)
+    # (sense widths up to 640 are taken since ABI 8 -- csrc/sense_wide.hip; the gathering form takes 160 / 640 of them, ABI 9)
     assert h.bp_sense_mix(p, p, p, p, 0, 1, 16, 4, 648, 64, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0.25, 1, null, null) == -2
     assert h.bp_sense_lse(p, p, 1, 16, 4, 641, 1, 1, 1, 1, 0.25, 1, null) == -2
+    # the gathering form beyond 128: only 160 / 640 at a sequence length that is a multiple of 32
+    gather_tail = (8, 8, 8, 8, 8, 8, 8, 8, 8, 0.25, 1, null, null)
+    assert h.bp_sense_mix_gather(p, p, p, p, p, 1, 1, 64, 2, 136, 64, 100, *gather_tail) == -2
+    assert h.bp_sense_mix_gather(p, p, p, p, p, 1, 1, 40, 2, 160, 64, 100, *gather_tail) == -2
+    assert h.bp_sense_mix_gather(p, p, p, null, p, 1, 1, 64, 2, 160, 64, 100, *gather_tail) == -3   # taken: stops at the NULL out
     assert h.bp_sense_alpha(p, p, p, 0, 1, 16, 4, 0, 1, 1, 1, 1, 0.25, 1, null) == -2
     # a misaligned queue_ws
     assert h.bp_sense_mix(p, p, p, p, 0, 1, 16, 4, 16, 64, 8, 8, 8, 8, 8, 8, 8, 8, 8, 0.25, 1, ctypes.c_void_p(0x1004),

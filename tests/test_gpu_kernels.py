@@ -799,6 +799,47 @@ def test_wide_senses_lse_alpha_and_mix(shape, dtype):
     assert torch.equal(bp.sense_mix(big[:, :, :, :k, :dk], c.to(DEV)), out) or dk % 8 != 0
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [
+    # (B, S, k, d_k, d_out, table rows): the reference's two few-sense widths on the ring kernels of csrc/sense_wide_dma.hip
+    (2, 1024, 4, 160, 640, 3000),      # backpack-mini-flash-vecs-4.yaml
+    (2, 1024, 1, 640, 640, 70000),     # ...-vecs-1.yaml; more than 65 536 rows (the narrow kernel's u16 limit does not apply)
+    (3, 96, 4, 160, 200, 17),          # one partial query tile, d_out not a multiple of 320
+])
+def test_wide_senses_mix_gathers_from_the_table(shape, dtype):
+    """bp_sense_mix_gather at d_k = 160 / 640 (ABI 9): the content rows read from the per-token table inside the ring kernel
+    give the BITS of bp_sense_mix on the gathered (B,S,k,d) tensor (same kernel, same order of operations); indices outside
+    the table are clamped to its last row; widths the ring does not take are refused (the caller gathers)."""
+    bp = _bp()
+    b, s, k, dk, dout, rows = shape
+    torch.manual_seed(rows)
+    qk = (torch.randn(b, s, 2, k, dk, device=DEV) * (2.0 / dk ** 0.25)).to(dtype)
+    table = torch.randn(rows, k, dout, device=DEV).to(dtype)
+    index = torch.randint(0, rows, (b, s), device=DEV, dtype=torch.int32)
+    index[0, 0], index[-1, -1] = rows - 1, 0
+    assert bp.sense_mix_gather_supported(qk, table, s)
+    lse = bp.sense_lse(qk)
+    want = bp.sense_mix(qk, table[index.long()], lse=lse)
+    got = bp.sense_mix_gather(qk, table, index, lse=lse)
+    assert torch.equal(got, want)
+    assert torch.equal(bp.sense_mix_gather(qk, table, index), want)            # LSE computed inside the call
+    bad = index.clone()
+    bad[0, 1], bad[-1, 5] = -3, rows + 11                                       # both read the LAST row
+    fixed = index.clone()
+    fixed[0, 1], fixed[-1, 5] = rows - 1, rows - 1
+    assert torch.equal(bp.sense_mix_gather(qk, table, bad, lse=lse), bp.sense_mix(qk, table[fixed.long()], lse=lse))
+    # a table with padded rows (a slice of a wider buffer), as the cached sense table may be
+    wide_table = torch.zeros(rows, k + 1, dout + 8, device=DEV, dtype=dtype)
+    wide_table[:, :k, :dout] = table
+    assert torch.equal(bp.sense_mix_gather(qk, wide_table[:, :k, :dout], index, lse=lse), want)
+    # not taken: another width, a sequence length that is not a multiple of 32
+    other = torch.randn(1, 64, 2, 2, 136, device=DEV).to(dtype)
+    assert not bp.sense_mix_gather_supported(other, table[:, :2], 64)
+    assert not bp.sense_mix_gather_supported(qk[:, :40], table, 40)
+    with pytest.raises(RuntimeError, match='bp_sense_mix_gather'):
+        bp.sense_mix_gather(qk[:, :40], table, index[:, :40].contiguous())
+
+
 def test_wide_senses_backward_runs_without_opt_in():
     """SenseMixFn at d_k = 160: forward on the wide kernels, backward through the alpha-rebuilding route (alpha is small with
     few senses) WITHOUT `allow_eager_fallback` -- gradients against fp32 autograd of the oracle's ops."""
