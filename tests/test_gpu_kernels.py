@@ -223,6 +223,37 @@ def test_sense_mix_golden(tag):
     rel_check(out, want, eager, f'mix {tag}')
 
 
+@pytest.mark.parametrize('tag', ['dk160', 'dk640'])
+def test_wide_sense_golden(tag):
+    """G9: alpha and the fused mix at the reference's few-sense widths (d_k = 160 / 640: the ring kernels of
+    csrc/sense_wide_dma.hip compute the LSE and the mix, sense_wide.hip dumps alpha) against the REFERENCE's own
+    ContextSelfAttn output and `torch.sum(alpha @ content, 1)` (tests/golden/make_golden_r6.py)."""
+    bp = _bp()
+    g = load_golden('g9_wide_sense.npz')
+    w, b, h = from_bits16(g[f'{tag}_w']), from_bits16(g[f'{tag}_b']), from_bits16(g[f'{tag}_h'])
+    k = int(g[f'{tag}_k'])
+    qk16 = torch.nn.functional.linear(h, w, b).reshape(h.shape[0], h.shape[1], 2, k, -1).bfloat16()
+    assert qk16.shape[-1] == int(tag[2:]) and qk16.shape[1] % 32 == 0
+    c16 = from_bits16(g[f'{tag}_content']).bfloat16()                        # (B,S,k,dout) storage layout
+    want_alpha = R.sense_alpha_from_qk(qk16.float())
+    alpha = bp.sense_alpha(qk16.to(DEV))
+    rel_check(alpha, want_alpha, R.sense_alpha_from_qk(qk16), f'G9 alpha {tag}', atol=4e-3)
+    s = alpha.shape[-1]
+    assert torch.count_nonzero(alpha.cpu()[:, :, torch.triu(torch.ones(s, s, dtype=torch.bool), 1)]) == 0
+    assert (alpha.float().cpu() - torch.from_numpy(g[f'{tag}_alpha'])).abs().max().item() < 0.05   # (input rounding of qk)
+    want = R.sense_mix_from_qk_fp32(qk16, c16.transpose(1, 2))
+    eager = R.sense_mix(R.sense_alpha_from_qk(qk16), c16.transpose(1, 2))
+    out = bp.sense_mix(qk16.to(DEV), c16.to(DEV))
+    rel_check(out, want, eager, f'G9 mix {tag}')
+    ref_mixed = torch.from_numpy(g[f'{tag}_mixed'])
+    assert (out.float().cpu() - ref_mixed).abs().max().item() < 0.05 * max(1.0, ref_mixed.abs().max().item())
+    lse = bp.sense_lse(qk16.to(DEV))[:, :, :s].cpu()
+    q32, k32 = qk16[:, :, 0].float().transpose(1, 2), qk16[:, :, 1].float().transpose(1, 2)
+    scores = (q32 @ k32.transpose(2, 3) * qk16.shape[-1] ** -0.5).masked_fill(
+        torch.triu(torch.ones(s, s, dtype=torch.bool), 1), float('-inf'))
+    assert (lse - torch.logsumexp(scores, -1)).abs().max().item() < 2e-3
+
+
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('shape', [
     # (B, S, k, d_k, d_out)
@@ -761,6 +792,8 @@ def test_sense_mix_gather_refuses_what_it_does_not_take():
     (2, 129, 2, 132, 100),     # d_k % 8 != 0: widened to 136 by the binding; odd d_out (element-wise stores)
     # the staged kernels' K loop run to its compile-time end (no early exit): the paths on which the round-6 listing scan
     # found MFMA results read 3 of 11 wait states early (bp_common.h, settle_acc)
+    (1, 32, 4, 160, 64),       # ring kernels at their smallest: one key block, one wave with rows
+    (2, 2080, 1, 640, 320),    # ... and past 2048 keys (65 key blocks per sweep), one 320-column chunk
     (1, 160, 1, 192, 64),      # d_k = 192 = the whole small class
     (1, 96, 1, 640, 72),       # d_k = 640 off the ring kernels (S not a multiple of 32), the whole large class
     (2, 1024, 4, 160, 640, 'view'),   # d_k = 160 on a 4-byte-aligned view: the staged kernels' element-wise loaders at 160

@@ -31,6 +31,25 @@ def test_g1_g2_sense_alpha_and_mix():
         assert (fused - mixed).abs().max().item() < 1e-5
 
 
+def test_g9_wide_sense_alpha_and_mix():
+    """G9 (make_golden_r6.py): the reference's ContextSelfAttn and sense combination at the widths of its few-sense
+    ablation configs (d_k = 160 / 640), the shapes csrc/sense_wide_dma.hip runs."""
+    g = load_golden('g9_wide_sense.npz')
+    for tag in ('dk160', 'dk640'):
+        w, b, h = from_bits16(g[f'{tag}_w']), from_bits16(g[f'{tag}_b']), from_bits16(g[f'{tag}_h'])
+        k = int(g[f'{tag}_k'])
+        assert w.shape[1] // k == int(tag[2:])
+        alpha = R.context_self_attn(h, w, b, k)
+        assert (alpha - torch.from_numpy(g[f'{tag}_alpha'])).abs().max().item() < 1e-6
+        assert torch.count_nonzero(torch.triu(alpha, 1)) == 0
+        content = from_bits16(g[f'{tag}_content']).transpose(1, 2)
+        mixed = R.sense_mix(alpha, content)
+        assert (mixed - torch.from_numpy(g[f'{tag}_mixed'])).abs().max().item() < 1e-5
+        fused = R.sense_mix_from_qk_fp32(torch.nn.functional.linear(h, w, b).reshape(
+            h.shape[0], h.shape[1], 2, k, -1), content)
+        assert (fused - mixed).abs().max().item() < 1e-5
+
+
 def test_g3_trunk_attention():
     g = load_golden('g3_trunk_attn.npz')
     for tag in ('h64', 'h80'):
