@@ -108,8 +108,12 @@ def test_sense_kernels_on_drawn_shapes(seed):
     s = rnd.choice([1, 2, 31, 33, 63, 64, 65, 255, 256, 257, rnd.randint(1, 600), rnd.randint(1, 600)])
     k = rnd.randint(1, 20)
     dk = rnd.choice([8, 16, 24, 32, 40, 48, 56, 64, 10, 20, 12])
-    if rnd.random() < 0.2:      # wide senses (round 6, csrc/sense_wide.hip): few of them, 129 ... 640 wide, unaligned ones too
+    if rnd.random() < 0.2 or os.environ.get('BP_FUZZ_RING') == '1':   # wide senses (round 6, csrc/sense_wide.hip): few of them, 129 ... 640 wide, unaligned ones too
         k, dk = rnd.randint(1, 4), rnd.choice([136, 160, 192, 200, 320, 636, 640, 130, 250])
+        if rnd.random() < 0.5 or os.environ.get('BP_FUZZ_RING') == '1':
+            # the two widths of the reference's few-sense configs at a length that is a multiple of 32: the LDS-DMA ring
+            # kernels of csrc/sense_wide_dma.hip (dense and table form); BP_FUZZ_RING=1 makes a hunt draw only these
+            dk, s = rnd.choice([160, 640]), 32 * rnd.randint(1, 24)
         qk_amp = 1.3 * (64 / dk) ** 0.25
     else:
         qk_amp = 1.3
