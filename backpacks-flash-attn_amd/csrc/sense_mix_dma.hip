@@ -35,6 +35,14 @@
 #include "bp_dma.h"
 #include "bp_kernels.h"
 
+// the dense content stream: read once per job under the shipped ticket order -> non-temporal; the paired-ticket probe
+// (BP_MIX_ORDER == 2) WANTS the group's other workgroups to hit these lines in the L2
+#if defined(BP_MIX_ORDER) && BP_MIX_ORDER == 2
+#define BP_MIX_CONTENT_DMA dma16_s
+#else
+#define BP_MIX_CONTENT_DMA dma16_s_nt
+#endif
+
 namespace bp {
 
 // Development builds only (-DBP_MIX_PROFILE, scripts/probes/mix_timeline): every wave adds up the s_memtime ticks its
@@ -120,7 +128,34 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
     MixQueues *queues = p.queues;
     uint32_t exhausted = 0;   // bit q: queue q has no jobs left (wave-uniform, only thread 0 uses it)
     const int my_xcd = blockIdx.x & 7;
+#if defined(BP_MIX_ORDER) && BP_MIX_ORDER == 2
+    // Paired tickets (probe): a ticket is the PAIR of query tiles (n-1-t, t) of one (sample, column chunk) group -- the long one
+    // first, the short one right behind it on the same workgroup -- and a group's pairs are consecutive tickets.  Every
+    // ticket of a group then costs the same (n + 1 tile sweeps), the group's workgroups start together at key 0 and stream
+    // the same content rows in step: one fetch from HBM, the rest L2 hits, where heaviest-first re-streams every tile.
+    int pending = -1;         // the short tile of my current ticket (thread 0 only)
+    const int n_pairs = (p.n_qtiles + 1) / 2;
+#endif
     auto next_job = [&]() -> int {   // thread 0 only; returns grp * 256 + qt, or -1
+#if defined(BP_MIX_ORDER) && BP_MIX_ORDER == 2
+        if (pending >= 0) { const int j = pending; pending = -1; return j; }
+        for (int t = 0; t < 8; ++t) {
+            const int q = (my_xcd + t) & 7;
+            if (exhausted & (1u << q)) continue;
+            const int groups = mix_queue_groups(p.b, p.n_chunks, q);
+            const int njobs = groups * n_pairs;
+            const int idx = njobs > 0 ? (int)atomicAdd(&queues->ticket[q], 1u) : njobs;
+            if (idx < njobs) {
+                const int gl = idx / n_pairs, pr = idx - gl * n_pairs;
+                const int grp = mix_queue_group(p.n_chunks, q, gl);
+                const int lng = p.n_qtiles - 1 - pr;
+                if (pr != lng) pending = grp * 256 + pr;
+                return grp * 256 + lng;
+            }
+            exhausted |= 1u << q;
+        }
+        return -1;
+#endif
         for (int t = 0; t < 8; ++t) {
             const int q = (my_xcd + t) & 7;
             if (exhausted & (1u << q)) continue;
@@ -254,8 +289,8 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
                             continue;
                         }
                         const uint32_t back = (uint32_t)(max(c_piece_row(j) - last_row, 0) * p.c_rs) * 2u;
-                        dma16_s_nt(ct2, c_voff[j] - back,
-                                   __builtin_amdgcn_readfirstlane(stage_off + C::KTILE + (wave * C::C_DMA + j) * 1024));
+                        BP_MIX_CONTENT_DMA(ct2, c_voff[j] - back,
+                                           __builtin_amdgcn_readfirstlane(stage_off + C::KTILE + (wave * C::C_DMA + j) * 1024));
                     }
             } else {
 #pragma unroll
@@ -266,7 +301,7 @@ __global__ __launch_bounds__(512) void sense_mix_dma_kernel(const MixParams p) {
                     if ((pieces >> (C::K_DMA + j)) & 1u) {
                         if (GATHER) gather_piece(j, stage_off + C::KTILE + (wave * C::C_DMA + j) * 1024);
                         // the content stream is read once per job: non-temporal (-1.6 % at B=64, r02_p)
-                        else dma16_s_nt(ct2, c_voff[j], stage_off + C::KTILE + (wave * C::C_DMA + j) * 1024);
+                        else BP_MIX_CONTENT_DMA(ct2, c_voff[j], stage_off + C::KTILE + (wave * C::C_DMA + j) * 1024);
                     }
             }
             if (WEIGHTED && ((pieces >> (C::K_DMA + C::C_DMA)) & 1u)) {
