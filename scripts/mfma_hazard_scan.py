@@ -84,14 +84,22 @@ def functions(text):
         yield name, cur
 
 
-def scan(name, ins, verbose=False):
+TRANS = ('v_exp_', 'v_log_', 'v_rcp_', 'v_rsq_', 'v_sqrt_', 'v_sin_', 'v_cos_')
+
+
+def scan(name, ins, verbose=False, trans=True):
+    """Early reads behind every v_mfma (passes + 3 wait states) and, with `trans`, behind every transcendental: gfx940+
+    forwards a transcendental's result to another transcendental only; a plain VALU that reads it needs ONE wait state in
+    between (LLVM's hasTransForwardingHazard), and the same only-inside-a-block padding could miss it across a branch."""
     by_addr = {a: i for i, (a, _, _) in enumerate(ins)}
     found = []
     for i, (addr, mn, ops) in enumerate(ins):
-        if not mn.startswith('v_mfma') and not mn.startswith('v_smfmac'):
+        is_mfma = mn.startswith('v_mfma') or mn.startswith('v_smfmac')
+        is_trans = trans and mn.startswith(TRANS)
+        if not is_mfma and not is_trans:
             continue
         dst = regs(ops.split(',')[0])
-        need = passes(mn) + 3
+        need = passes(mn) + 3 if is_mfma else 1
         seen = set()
         stack = [(i + 1, 0)]
         while stack:
@@ -108,6 +116,8 @@ def scan(name, ins, verbose=False):
                     used = set()
                 else:
                     used = regs(ops2)
+                if is_trans and (mn2.startswith(TRANS) or not mn2.startswith('v_')):
+                    used = set()     # forwarded to another transcendental; memory / LDS / scalar readers are interlocked
                 if used & dst and not mn2.startswith('s_'):
                     found.append((name, addr, mn, a2, mn2 + ' ' + ops2, states, need))
                     break
@@ -150,7 +160,7 @@ def main():
                 dem = subprocess.run(['c++filt', h[0]], capture_output=True, text=True).stdout.strip()
                 print('%s: %s\n    %s at %#x -> read by `%s` at %#x after %d of %d wait states'
                       % (os.path.basename(obj), dem[:110], h[2], h[1], h[4][:70], h[3], h[5], h[6]))
-    print('early reads of MFMA results: %d' % total)
+    print('early reads of MFMA / transcendental results: %d' % total)
     return total
 
 

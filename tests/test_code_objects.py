@@ -88,6 +88,32 @@ def test_resource_table_lists_every_object(table):
     assert all('vgpr_count' in k and 'sgpr_spill_count' in k for k in table.values())
 
 
+def test_hazard_scanner_flags_what_it_should():
+    """scripts/mfma_hazard_scan.py on hand-made listings: the round-6 finding (a VALU read of an MFMA result one slot behind
+    the loop's back-edge) and its cures are told apart; a transcendental's result read by the next plain VALU is flagged,
+    forwarded to another transcendental or one instruction later it is not."""
+    import mfma_hazard_scan as HS
+
+    def listing(lines):
+        return [(0x1000 + 4 * i, mn, ops) for i, (mn, ops) in enumerate(lines)]
+    mfma = ('v_mfma_f32_32x32x16_bf16', 'v[0:15], v[66:69], v[44:47], v[0:15]')
+    # block at 0x1000 is the loop head; the MFMA sits at index 3, the back-edge right behind it: offset = -(5 words)
+    bad = listing([('v_max_f32_e32', 'v59, v3, v3'), ('s_nop', '7'), ('v_max3_f32', 'v65, v0, v1, v4'),
+                   mfma, ('s_cbranch_scc1', str(65536 - 5)), ('s_endpgm', '')])
+    assert [h[4].split()[0] for h in HS.scan('bad', bad)] == ['v_max_f32_e32']
+    padded = listing([('v_max_f32_e32', 'v59, v3, v3'), mfma, ('s_nop', '7'), ('s_nop', '3'),
+                      ('s_cbranch_scc1', str(65536 - 5)), ('s_endpgm', '')])
+    assert HS.scan('padded', padded) == []
+    chain = listing([mfma, mfma, ('s_nop', '7'), ('s_nop', '2'), ('v_add_f32_e32', 'v20, v0, v1'), ('s_endpgm', '')])
+    assert HS.scan('chain', chain) == []            # the accumulator operand of the next MFMA is forwarded in hardware
+    assert HS.passes('v_mfma_f32_32x32x16_bf16') == 8 and HS.passes('v_mfma_f32_16x16x32_f16') == 4
+    trans_bad = listing([('v_exp_f32_e32', 'v1, v0'), ('v_add_f32_e32', 'v2, v1, v1'), ('s_endpgm', '')])
+    assert len(HS.scan('t', trans_bad)) == 1
+    trans_ok = listing([('v_exp_f32_e32', 'v1, v0'), ('v_exp_f32_e32', 'v3, v1'), ('v_mov_b32_e32', 'v9, v8'),
+                        ('v_add_f32_e32', 'v2, v3, v3'), ('s_endpgm', '')])
+    assert HS.scan('t', trans_ok) == []
+
+
 def test_no_vector_instruction_reads_an_mfma_result_early(table):
     """gfx950 does not interlock "matrix pipe writes a VGPR -> VALU reads it"; hipcc pads the gap with s_nop, but not
     reliably across a branch (csrc/bp_common.h, settle_acc: found in round 6 as a one-ulp launch-to-launch variation of the
