@@ -75,7 +75,11 @@ def test_flash_fwd_causality_sample_independence_determinism(name, b, s, h, d, d
 # (name, batch, seq, senses, d_k, d, dtype): the sense kernels of BASELINE configs 2, 4 and 5
 MIX_SHAPES = [('small-1024', 12, 1024, 16, 48, 768, torch.bfloat16),
               ('mini-k64-1024', 4, 1024, 64, 10, 640, torch.bfloat16),
-              ('small-4096-fp16', 2, 4096, 16, 48, 768, torch.float16)]
+              ('small-4096-fp16', 2, 4096, 16, 48, 768, torch.float16),
+              # the reference's few-sense widths on the LDS-DMA ring kernels of csrc/sense_wide_dma.hip (bench workloads
+              # mini-k4-1024 / mini-k1-1024)
+              ('mini-k4-1024', 6, 1024, 4, 160, 640, torch.bfloat16),
+              ('mini-k1-1024', 6, 1024, 1, 640, 640, torch.float16)]
 
 
 @pytest.mark.parametrize('name,b,s,k,dk,d,dtype', MIX_SHAPES, ids=[x[0] for x in MIX_SHAPES])
