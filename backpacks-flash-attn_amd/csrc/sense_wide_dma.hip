@@ -10,11 +10,13 @@
 // (registers -> LDS, one __syncthreads per key block, 128 output columns per workgroup: S^T recomputed five times for
 // d = 640, every MFMA behind its own LDS round trip):
 //   * the K rows and the content rows of a 32-key block reach LDS by DMA (`global_load_lds_dwordx4`, bp_dma.h) into a
-//     ring of 2 to 4 slots: blocks i + 1 .. i + RING - 1 are in flight while block i is multiplied (with 0.6 us of MFMAs per
-//     block and ~2.4 us of DMA latency under load a two-slot ring waits for every block: d_k = 160 went 9.3 -> X ms at
-//     B = 1024 with four slots); counted vmcnt, one s_barrier per block;
-//   * a workgroup covers NB * 32 = 320 (or 160) output columns, so S^T and the exponentials are recomputed 2 (4) times per
-//     query block instead of 5;
+//     ring: block i + 1 is in flight while block i is multiplied; one s_barrier per block.  RING is a template parameter (2 to
+//     4 slots with a counted vmcnt); three and four slots measured nothing over two (d_k = 160, B = 1024: 6.07 / 6.19 / 6.19
+//     ms, profiles/r06_i_*), so two are shipped and every wait drains the ring;
+//   * a workgroup covers NB * 32 = 320 output columns, so S^T and the exponentials are recomputed twice per query block
+//     instead of five times; d_k = 160 runs eight waves per workgroup (256 queries share a block's rows; 4 waves x 320
+//     columns: 7.96 ms, 8 waves x 160 columns: 9.3 ms, 8 x 320: 6.15 ms, profiles/r06_h_*), d_k = 640 four (its 160 fragment
+//     and 160 accumulator registers leave one wave per SIMD);
 //   * the LDS operands of both MFMA runs are requested two MFMAs ahead (mfma_stream, bp_common.h);
 //   * the K image has an ODD row pitch (2 KD + 1 sixteen-byte slots): b128 reads of 16 consecutive rows touch every bank
 //     once; the content image is XOR-swizzled on the DMA's source side for ds_read_b64_tr_b16.
