@@ -27,9 +27,9 @@
 
 namespace bp {
 
-template <int KD, int NW, int NB, int RING = 2>
+template <int KD, int NW, int NB, int RING = 2, int SUB = 1>
 struct WideDmaCfg {
-    static constexpr int BK = 32;                      // keys per ring step
+    static constexpr int BK = 32 * SUB;                // keys per ring step: SUB 32-key blocks (one S^T / P V run each)
     static constexpr int NT = NW * 64;
     static constexpr int BM = NW * 32;                 // queries per workgroup (a wave owns 32)
     static constexpr int KSLOTS = 2 * KD + 1;          // 16-byte slots per K row, one of them padding (odd pitch)
@@ -61,9 +61,9 @@ template <int NB> BP_DEV int wide_c_off(int row, int ch) {
 }
 
 // The ring: per-lane source offsets of my DMA pieces (constant over the sweep), and the issue of one step's pieces.
-template <int KD, int NW, int NB, int RING = 2>
+template <int KD, int NW, int NB, int RING = 2, int SUB = 1>
 struct WideRing {
-    using C = WideDmaCfg<KD, NW, NB, RING>;
+    using C = WideDmaCfg<KD, NW, NB, RING, SUB>;
     uint32_t voff[C::NPW];
     // GATHER: the content rows are rows of a table picked by an index per key (bp_sense_mix_gather).  A content piece's
     // descriptor is then (row of the block) << 16 | byte offset of its column inside the chunk; the table row's byte offset
@@ -148,9 +148,9 @@ template <int KD> BP_DEV void wide_dma_load_q(u32x4 (&qf)[KD], const uint16_t *q
 }
 
 // ---- fused mix ---------------------------------------------------------------------------------------------------------
-template <class ET, int KD, int NW, int NB, int RING, bool GATHER>
+template <class ET, int KD, int NW, int NB, int RING, bool GATHER, int SUB>
 __global__ __launch_bounds__(NW * 64) void sense_mix_wide_dma_kernel(const MixParams p) {
-    using C = WideDmaCfg<KD, NW, NB, RING>;
+    using C = WideDmaCfg<KD, NW, NB, RING, SUB>;
     using E = Elem<ET>;
     constexpr int kIdsOff = RING * C::STAGE;           // GATHER: the job's row indices behind the ring, 4 bytes per key
     static_assert(!GATHER || kIdsOff + kMixGatherMaxKeys * 4 <= 160 * 1024, "LDS budget");
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(NW * 64) void sense_mix_wide_dma_kernel(const MixPa
     const uint16_t *kg = reinterpret_cast<const uint16_t *>(p.k) + batch * p.qk_bs;
     const uint16_t *cg = reinterpret_cast<const uint16_t *>(p.c) + batch * p.c_bs;   // (GATHER: the table, c_bs = 0)
     const int k_end = min(S, qt * C::BM + C::BM);
-    const int nkb = k_end / C::BK;                    // S % 32 == 0 (launcher)
+    const int nkb = k_end / C::BK;                    // S % BK == 0 (launcher)
     const int nsteps = p.nsenses * nkb;
     if (GATHER) {   // my keys' table rows, clamped as unsigned values (a negative or too large index reads the LAST row)
         const int32_t *idx = p.row_index + batch * p.idx_bs;
@@ -180,11 +180,11 @@ __global__ __launch_bounds__(NW * 64) void sense_mix_wide_dma_kernel(const MixPa
     }
     const int q0 = qt * C::BM + wave * 32, my_q = q0 + l31;
     const bool wave_has_rows = q0 < S;                // then every row of the wave exists
-    const int my_last_kb = q0 / C::BK;
+    const int my_last_kb = q0 / 32;                   // in 32-key blocks
     const float c2 = p.scale_log2e;
     const int nb_live = min(NB, (p.dout - col_base + 31) / 32);
 
-    WideRing<KD, NW, NB, RING> ring;
+    WideRing<KD, NW, NB, RING, SUB> ring;
     ring.setup(wave, lane, p.qk_rs, p.c_rs, col_base, p.dout, GATHER);
     int l_i = 0, kb_i = 0, slot_i = 0;                // (sense, key block) and ring slot of the next issue
     auto issue = [&]() {
@@ -235,13 +235,16 @@ __global__ __launch_bounds__(NW * 64) void sense_mix_wide_dma_kernel(const MixPa
             settle(lse2);
         }
         if (step + RING - 1 < nsteps) issue();
-        const char *kbuf = smem + slot_r * C::STAGE;
+        const char *stage = smem + slot_r * C::STAGE;
         if (++slot_r == RING) slot_r = 0;
-        if (wave_has_rows && kb <= my_last_kb) {
-            const char *cbuf = kbuf + C::KREGION;
+#pragma unroll
+        for (int sub = 0; sub < SUB; ++sub)
+        if (wave_has_rows && kb * SUB + sub <= my_last_kb) {
+            const char *kbuf = stage + sub * 32 * C::KROW;
+            const char *cbuf = stage + C::KREGION + sub * 32 * C::CROW;
             f32x16 st = wide_dma_scores<ET, KD, C::KROW, (NW <= 4)>(kbuf, qf, l31, hh);
             u32x4 pf[2];
-            if (kb == my_last_kb) {        // the diagonal block: exact zeros above the diagonal
+            if (kb * SUB + sub == my_last_kb) {   // the diagonal block: exact zeros above the diagonal
                 const int lim = l31 - 4 * hh;   // my_q - kb * 32 - 4 hh
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
@@ -295,9 +298,9 @@ __global__ __launch_bounds__(NW * 64) void sense_mix_wide_dma_kernel(const MixPa
 }
 
 // ---- LSE ---------------------------------------------------------------------------------------------------------------
-template <class ET, int KD, int NW, int RING>
+template <class ET, int KD, int NW, int RING, int SUB>
 __global__ __launch_bounds__(NW * 64) void sense_lse_wide_dma_kernel(const MixParams p, float *lse_out) {
-    using C = WideDmaCfg<KD, NW, 0, RING>;
+    using C = WideDmaCfg<KD, NW, 0, RING, SUB>;
     __shared__ __attribute__((aligned(16))) char smem[RING * C::STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
@@ -314,10 +317,10 @@ __global__ __launch_bounds__(NW * 64) void sense_lse_wide_dma_kernel(const MixPa
     const int nkb = k_end / C::BK;
     const int q0 = qt * C::BM + wave * 32, my_q = q0 + l31;
     const bool wave_has_rows = q0 < S;
-    const int my_last_kb = q0 / C::BK;
+    const int my_last_kb = q0 / 32;                   // in 32-key blocks
     const float c2 = p.scale_log2e;
 
-    WideRing<KD, NW, 0, RING> ring;
+    WideRing<KD, NW, 0, RING, SUB> ring;
     ring.setup(wave, lane, p.qk_rs, 0, 0, 0);
     u32x4 qf[KD];
     if (wave_has_rows) wide_dma_load_q<KD>(qf, qg + (int64_t)min(my_q, S - 1) * p.qk_rs, hh);
@@ -339,11 +342,13 @@ __global__ __launch_bounds__(NW * 64) void sense_lse_wide_dma_kernel(const MixPa
 #endif
         __builtin_amdgcn_s_barrier();
         if (kb + RING - 1 < nkb) issue();
-        const char *kbuf = smem + slot_r * C::STAGE;
+        const char *stage = smem + slot_r * C::STAGE;
         if (++slot_r == RING) slot_r = 0;
-        if (wave_has_rows && kb <= my_last_kb) {
-            f32x16 st = wide_dma_scores<ET, KD, C::KROW, (NW <= 4)>(kbuf, qf, l31, hh);
-            if (kb == my_last_kb) {
+#pragma unroll
+        for (int sub = 0; sub < SUB; ++sub)
+        if (wave_has_rows && kb * SUB + sub <= my_last_kb) {
+            f32x16 st = wide_dma_scores<ET, KD, C::KROW, (NW <= 4)>(stage + sub * 32 * C::KROW, qf, l31, hh);
+            if (kb * SUB + sub == my_last_kb) {
                 const int lim = l31 - 4 * hh;
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
@@ -392,6 +397,10 @@ __global__ __launch_bounds__(NW * 64) void sense_lse_wide_dma_kernel(const MixPa
 #define BP_WIDE640_LSE_RING 2
 #endif
 
+#ifndef BP_WIDE160_SUB   // 32-key blocks per ring step at d_k = 160 when the length allows (s % (32 SUB) == 0)
+#define BP_WIDE160_SUB 1
+#endif
+
 bool sense_wide_dma_takes(int s, int dk, int dout, bool vec_qk, bool vec_c, bool weighted) {
 #ifdef BP_WIDE_NO_DMA   // variant build for A/B runs: everything wide on the staged kernels of sense_wide.hip
     return false;
@@ -399,32 +408,36 @@ bool sense_wide_dma_takes(int s, int dk, int dout, bool vec_qk, bool vec_c, bool
     return vec_qk && vec_c && !weighted && (dk == 160 || dk == 640) && s % 32 == 0 && s > 0 && dout % 8 == 0;
 }
 
-template <class ET, int KD, int NW, int NB, int RING>
+template <class ET, int KD, int NW, int NB, int RING, int SUB>
 static hipError_t launch_mix_wide_dma_cfg(const MixParams &p, hipStream_t stream) {
-    using C = WideDmaCfg<KD, NW, NB, RING>;
+    using C = WideDmaCfg<KD, NW, NB, RING, SUB>;
     const int n_qtiles = (p.s + C::BM - 1) / C::BM;
     const int n_chunks = (p.dout + NB * 32 - 1) / (NB * 32);
     const dim3 grid(xcd_grid(p.b * n_chunks, n_qtiles)), block(C::NT);
     if (p.row_index != nullptr)
-        hipLaunchKernelGGL((sense_mix_wide_dma_kernel<ET, KD, NW, NB, RING, true>), grid, block, 0, stream, p);
+        hipLaunchKernelGGL((sense_mix_wide_dma_kernel<ET, KD, NW, NB, RING, true, SUB>), grid, block, 0, stream, p);
     else
-        hipLaunchKernelGGL((sense_mix_wide_dma_kernel<ET, KD, NW, NB, RING, false>), grid, block, 0, stream, p);
+        hipLaunchKernelGGL((sense_mix_wide_dma_kernel<ET, KD, NW, NB, RING, false, SUB>), grid, block, 0, stream, p);
     return hipGetLastError();
 }
 
 hipError_t launch_sense_mix_wide_dma(const MixParams &p, int dtype, hipStream_t stream) {
+    if (p.dk == 160 && BP_WIDE160_SUB > 1 && p.s % (32 * BP_WIDE160_SUB) == 0)
+        return dtype == 1
+                   ? launch_mix_wide_dma_cfg<BF16, 10, BP_WIDE160_NW, BP_WIDE160_NB, BP_WIDE160_RING, BP_WIDE160_SUB>(p, stream)
+                   : launch_mix_wide_dma_cfg<F16, 10, BP_WIDE160_NW, BP_WIDE160_NB, BP_WIDE160_RING, BP_WIDE160_SUB>(p, stream);
     if (p.dk == 160)
-        return dtype == 1 ? launch_mix_wide_dma_cfg<BF16, 10, BP_WIDE160_NW, BP_WIDE160_NB, BP_WIDE160_RING>(p, stream)
-                          : launch_mix_wide_dma_cfg<F16, 10, BP_WIDE160_NW, BP_WIDE160_NB, BP_WIDE160_RING>(p, stream);
-    return dtype == 1 ? launch_mix_wide_dma_cfg<BF16, 40, 4, 10, 2>(p, stream)
-                      : launch_mix_wide_dma_cfg<F16, 40, 4, 10, 2>(p, stream);
+        return dtype == 1 ? launch_mix_wide_dma_cfg<BF16, 10, BP_WIDE160_NW, BP_WIDE160_NB, BP_WIDE160_RING, 1>(p, stream)
+                          : launch_mix_wide_dma_cfg<F16, 10, BP_WIDE160_NW, BP_WIDE160_NB, BP_WIDE160_RING, 1>(p, stream);
+    return dtype == 1 ? launch_mix_wide_dma_cfg<BF16, 40, 4, 10, 2, 1>(p, stream)
+                      : launch_mix_wide_dma_cfg<F16, 40, 4, 10, 2, 1>(p, stream);
 }
 
-template <class ET, int KD, int NW, int RING>
+template <class ET, int KD, int NW, int RING, int SUB>
 static hipError_t launch_lse_wide_dma_cfg(const MixParams &p, float *lse, hipStream_t stream) {
-    using C = WideDmaCfg<KD, NW, 0, RING>;
+    using C = WideDmaCfg<KD, NW, 0, RING, SUB>;
     const dim3 grid(xcd_grid(p.b * p.nsenses, (p.s + C::BM - 1) / C::BM)), block(C::NT);
-    hipLaunchKernelGGL((sense_lse_wide_dma_kernel<ET, KD, NW, RING>), grid, block, 0, stream, p, lse);
+    hipLaunchKernelGGL((sense_lse_wide_dma_kernel<ET, KD, NW, RING, SUB>), grid, block, 0, stream, p, lse);
     return hipGetLastError();
 }
 
@@ -434,11 +447,14 @@ hipError_t launch_sense_lse_wide_dma(const void *q, const void *k, float *lse, i
     MixParams p{};
     p.q = q; p.k = k; p.qk_bs = qk_bs; p.qk_rs = qk_rs; p.qk_ss = qk_ss;
     p.lse_stride = lse_stride; p.b = b; p.s = s; p.nsenses = nsenses; p.dk = dk; p.scale_log2e = scale_log2e;
+    if (dk == 160 && BP_WIDE160_SUB > 1 && s % (32 * BP_WIDE160_SUB) == 0)
+        return dtype == 1 ? launch_lse_wide_dma_cfg<BF16, 10, 8, BP_WIDE160_LSE_RING, BP_WIDE160_SUB>(p, lse, stream)
+                          : launch_lse_wide_dma_cfg<F16, 10, 8, BP_WIDE160_LSE_RING, BP_WIDE160_SUB>(p, lse, stream);
     if (dk == 160)
-        return dtype == 1 ? launch_lse_wide_dma_cfg<BF16, 10, 8, BP_WIDE160_LSE_RING>(p, lse, stream)
-                          : launch_lse_wide_dma_cfg<F16, 10, 8, BP_WIDE160_LSE_RING>(p, lse, stream);
-    return dtype == 1 ? launch_lse_wide_dma_cfg<BF16, 40, 4, BP_WIDE640_LSE_RING>(p, lse, stream)
-                      : launch_lse_wide_dma_cfg<F16, 40, 4, BP_WIDE640_LSE_RING>(p, lse, stream);
+        return dtype == 1 ? launch_lse_wide_dma_cfg<BF16, 10, 8, BP_WIDE160_LSE_RING, 1>(p, lse, stream)
+                          : launch_lse_wide_dma_cfg<F16, 10, 8, BP_WIDE160_LSE_RING, 1>(p, lse, stream);
+    return dtype == 1 ? launch_lse_wide_dma_cfg<BF16, 40, 4, BP_WIDE640_LSE_RING, 1>(p, lse, stream)
+                      : launch_lse_wide_dma_cfg<F16, 40, 4, BP_WIDE640_LSE_RING, 1>(p, lse, stream);
 }
 
 }  // namespace bp

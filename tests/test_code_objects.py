@@ -48,12 +48,12 @@ HOT = [
     ('sense_wide.o', 'sense_lse_wide_kernel<BF16, true, 40>', 1),
     # the same two configurations on the LDS-DMA ring (sense_wide_dma.hip): d_k = 160 as eight waves x 320 columns at two
     # waves per SIMD, d_k = 640 as four waves x 320 columns owning the file
-    ('sense_wide_dma.o', 'sense_mix_wide_dma_kernel<BF16, 10, 8, 10, 2, false>', 2),
-    ('sense_wide_dma.o', 'sense_mix_wide_dma_kernel<BF16, 40, 4, 10, 2, false>', 1),
-    ('sense_wide_dma.o', 'sense_mix_wide_dma_kernel<BF16, 10, 8, 10, 2, true>', 2),     # table form (inference)
-    ('sense_wide_dma.o', 'sense_mix_wide_dma_kernel<BF16, 40, 4, 10, 2, true>', 1),
-    ('sense_wide_dma.o', 'sense_lse_wide_dma_kernel<BF16, 10, 8, 2>', 4),
-    ('sense_wide_dma.o', 'sense_lse_wide_dma_kernel<BF16, 40, 4, 2>', 2),
+    ('sense_wide_dma.o', 'sense_mix_wide_dma_kernel<BF16, 10, 8, 10, 2, false, 1>', 2),
+    ('sense_wide_dma.o', 'sense_mix_wide_dma_kernel<BF16, 40, 4, 10, 2, false, 1>', 1),
+    ('sense_wide_dma.o', 'sense_mix_wide_dma_kernel<BF16, 10, 8, 10, 2, true, 1>', 2),     # table form (inference)
+    ('sense_wide_dma.o', 'sense_mix_wide_dma_kernel<BF16, 40, 4, 10, 2, true, 1>', 1),
+    ('sense_wide_dma.o', 'sense_lse_wide_dma_kernel<BF16, 10, 8, 2, 1>', 4),
+    ('sense_wide_dma.o', 'sense_lse_wide_dma_kernel<BF16, 40, 4, 2, 1>', 2),
 ]
 
 
