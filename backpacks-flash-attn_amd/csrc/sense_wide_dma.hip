@@ -397,7 +397,10 @@ __global__ __launch_bounds__(NW * 64) void sense_lse_wide_dma_kernel(const MixPa
 #define BP_WIDE640_LSE_RING 2
 #endif
 
-#ifndef BP_WIDE160_SUB   // 32-key blocks per ring step at d_k = 160 when the length allows (s % (32 SUB) == 0)
+// 32-key blocks per ring step at d_k = 160 when the length allows (s % (32 SUB) == 0).  Two blocks per step -- half the
+// barriers and waits, 61 KB stages -- measured SLOWER for the mix (6.13 -> 6.43 ms at B = 1024, table form 6.59 -> 6.68; LSE
+// 1.17 -> 1.15; profiles/r06_w_*): the barrier count is not what the step waits for.  One block per step is shipped.
+#ifndef BP_WIDE160_SUB
 #define BP_WIDE160_SUB 1
 #endif
 
