@@ -208,15 +208,31 @@ BP_DEV float xhalf_sum(float x) {
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
-// XCD-aware work mapping: the dispatcher places block L on XCD L % 8; give every XCD whole
-// `group`s of `per_group` consecutive work items so blocks that share K/V (or C) tiles also
-// share an L2.  Returns false for the padding blocks.
+// XCD-aware work mapping: the dispatcher places block L on XCD L % 8; give every XCD whole `group`s of `per_group` consecutive
+// work items so blocks that share K/V (or C) tiles also share an L2.  Returns false for the padding blocks.
+// Which groups an XCD takes: CONSECUTIVE ones -- XCD x takes groups [x n, (x + 1) n), n = ceil(ngroups / 8), in order (round
+// 6; rounds 1-5 dealt them round-robin, group g on XCD g % 8).  Groups are (sample, head) or (sample, sense) or (sample, column
+// chunk) pairs, and neighbours share memory: heads whose rows are narrower than or not aligned to a 128-byte line (d_h = 80:
+// 160-byte rows; the senses of the LSE pre-pass: 96- or 32-byte rows) share cache LINES, the column chunks of a sample share
+// all their K rows.  On one XCD, close in time, that sharing is L2 hits; dealt round-robin every L2 fetched it again: flash
+// forward at d_h = 80 10.8 -> 5.4 GB fetched per launch (-3.9 % time), LSE pre-pass at k = 64 21.8 -> 4.3 GB (-2.5 %: it is
+// bound by its exponentials), Small LSE -4.3 %, d_h = 64 (128-byte rows: nothing shared) -0.5 % (profiles/r06_z_*).
+// -DBP_XCD_SEQ=0 builds the round-robin deal for A/B runs.
+#ifndef BP_XCD_SEQ
+#define BP_XCD_SEQ 1
+#endif
 BP_DEV bool xcd_map(int block, int ngroups, int per_group, int &group, int &item) {
     const int xcd = block & 7;
     const int slot = block >> 3;
-    group = (slot / per_group) * 8 + xcd;
     item = slot % per_group;
+#if BP_XCD_SEQ
+    const int per_xcd = (ngroups + 7) >> 3;
+    group = xcd * per_xcd + slot / per_group;
+    return slot / per_group < per_xcd && group < ngroups;
+#else
+    group = (slot / per_group) * 8 + xcd;
     return group < ngroups;
+#endif
 }
 // Persistent sense-mix launches (forward and dC): jobs of queue q (one queue per XCD), heaviest query tile first.  A group is a (sample, column chunk) pair; ALL chunks
 // of a sample go to the queue sample mod 8, so the workgroups that stream the sample's K rows share one L2

@@ -11,8 +11,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def bench_name(kernel):
-    if kernel.startswith('bp::sense_mix_dma_kernel') or kernel.startswith('bp::sense_mix_kernel'):
+    if kernel.startswith(('bp::sense_mix_dma_kernel', 'bp::sense_mix_kernel', 'bp::sense_mix_wide')):
         return 'sense_mix_kernel'
+    if kernel.startswith('bp::sense_lse_wide'):
+        return 'flash_fwd_kernel[lse-only,senses]'
     m = re.match(r'bp::flash_fwd(_dma)?_kernel<bp::\w+, \d+, \d+, (true|false)', kernel)
     if m:
         return 'flash_fwd_kernel' if m.group(2) == 'true' else 'flash_fwd_kernel[lse-only,senses]'
